@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""Benchmark of the RAFT forward-prediction hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): image-pairs/sec at 448x512, iters_pred=24.  A "step" is one forward pass of
+RAFT over one batch of synthetic image pairs per GPU (BASELINE configs[1]: batch 4 per GPU,
+random Keras-default weights); all 24 upsampled predictions are produced, as the reference does.
+Inputs are generated on the device before the timed region.  With N > 1 every rank runs its own
+batch (weak scaling) and the final predictions are all-gathered over RCCL inside the timed region.
+
+Rank 0 prints ONE JSON line; besides the contract fields it carries
+  roofline            the dominant kernel (by accumulated time) with achieved / peak
+  roofline_corr_lookup the HBM-bound lookup kernel the north star singles out
+  stage_ms            per-kernel average milliseconds per launch (HIP events, instrumented replay)
+  cpu_baseline        the CPU oracle (reference restatement, torch-CPU) timed on this box's host cores
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W, ITERS = 448, 512, 24
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
+
+STAGES = ['corr_lookup', 'convc1', 'convc2', 'convf1', 'convf2', 'conv', 'gru_zr1', 'gru_q1', 'gru_zr2',
+          'gru_q2', 'fh1_mask0', 'fh2', 'mask2', 'upsample_convex']
+
+
+def stage_work(B, h, w):
+    """Algorithmic work per launch: MACs of the real (unpadded) convolution, or HBM bytes."""
+    M = B * h * w
+    macs = {
+        'convc1': 324 * 256, 'convc2': 9 * 256 * 192, 'convf1': 49 * 2 * 128, 'convf2': 9 * 128 * 64,
+        'conv': 9 * 256 * 126, 'gru_zr1': 5 * 384 * 256, 'gru_q1': 5 * 384 * 128, 'gru_zr2': 5 * 384 * 256,
+        'gru_q2': 5 * 384 * 128, 'fh1_mask0': 9 * 128 * 512, 'fh2': 9 * 256 * 2, 'mask2': 256 * 576,
+    }
+    flops = {k: 2.0 * v * M for k, v in macs.items()}
+    bytes_ = {
+        # 4 levels x (2r+2)^2 footprint reads + coords, 324 outputs written
+        'corr_lookup': M * (4 * 100 * 4 + 8 + 324 * 4),
+        # mask 576 + flow 2 read, 8x8x2 written
+        'upsample_convex': M * (576 * 4 + 8 + 64 * 2 * 4),
+    }
+    return flops, bytes_
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=4, help='image pairs per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-runs', type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)')
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    import tf_raft_amd
+    from tf_raft_amd import _dev, _ffi
+    from tf_raft_amd import weights as wm
+    from tf_raft_amd.layers.corr import CorrBlock
+    from tf_raft_amd.parallel import all_gather_batch
+
+    B = args.batch
+    wts = wm.init_weights('raft', seed=0)
+    model = tf_raft_amd.RAFT(iters_pred=ITERS, weights=wts)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1000 + rank)
+    img1 = torch.rand((B, H, W, 3), device=device, generator=gen) * 255.0
+    img2 = torch.rand((B, H, W, 3), device=device, generator=gen) * 255.0
+
+    def step(a=img1, b=img2):
+        preds = model([a, b], training=False)
+        if world > 1:
+            return all_gather_batch(preds[-1].as_subclass(torch.Tensor), world * B)
+        return preds[-1]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * B * args.steps / elapsed
+
+    result = {
+        'metric': 'image-pairs/sec at 448x512 iters_pred=24', 'value': round(value, 3), 'unit': 'image-pairs/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'RAFT forward, batch {B} per GPU at {H}x{W}, iters_pred={ITERS}, all {ITERS} '
+                               'upsampled predictions, random Keras-default weights (BASELINE configs[1])',
+                   'pairs_per_gpu': B, 'global_batch': world * B, 'parallelism': f'dp{world}',
+                   'collective': 'all_gather(flow_predictions[-1]) over RCCL' if world > 1 else 'none'},
+    }
+
+    if rank == 0:
+        # ---------------- instrumented replay: per-kernel HIP-event timing on the launch stream
+        h, w = H // 8, W // 8
+        x1 = 2 * (img1 / 255.0) - 1.0
+        x2 = 2 * (img2 / 255.0) - 1.0
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        fmap1, fmap2 = model.fnet([x1, x2])
+        ev[1].record()
+        cnet = model.cnet(x1)
+        ev[2].record()
+        corr = CorrBlock(fmap1, fmap2, num_levels=4, radius=4)
+        ev[3].record()
+        st = model._get_state(B, h, w, device)
+        model._prepare(cnet, st)
+        ev[4].record()
+        torch.cuda.synchronize()
+        pre_ms = {'fnet': ev[0].elapsed_time(ev[1]), 'cnet': ev[1].elapsed_time(ev[2]),
+                  'corr_build': ev[2].elapsed_time(ev[3]), 'prepare_state': ev[3].elapsed_time(ev[4])}
+        flow_up = torch.empty((ITERS, B, H, W, 2), device=device)
+        acc = np.zeros(len(STAGES), dtype=np.float64)
+        buf = (C.c_float * len(STAGES))()
+        reps = max(1, min(args.steps, 5))
+        for _ in range(reps):
+            model._prepare(cnet, st)
+            _ffi.check(_dev.lib().raft_iterate_basic_timed_f32(
+                C.byref(model.update_block.c), _dev.ptr(corr._pyr), corr._off, B, h, w, ITERS, C.byref(st.c),
+                _dev.ptr(flow_up), _dev.stream_ptr(), buf), 'iterate_basic_timed')
+            acc += np.array(list(buf), dtype=np.float64)
+        per_launch_ms = acc / (reps * ITERS)
+        stage_ms = {k: round(float(v), 5) for k, v in zip(STAGES, per_launch_ms)}
+        flops, bytes_ = stage_work(B, h, w)
+        dom = STAGES[int(np.argmax(acc))]
+        if dom in flops:
+            ach = flops[dom] / (stage_ms[dom] * 1e-3) / 1e12
+            roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'flops_per_launch': flops[dom], 'ms_per_launch': stage_ms[dom]}
+        else:
+            ach = bytes_[dom] / (stage_ms[dom] * 1e-3) / 1e9
+            roof = {'kernel': dom, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
+                    'bytes_per_launch': bytes_[dom], 'ms_per_launch': stage_ms[dom]}
+        result['roofline'] = roof
+        lk = bytes_['corr_lookup'] / (stage_ms['corr_lookup'] * 1e-3) / 1e9
+        result['roofline_corr_lookup'] = {
+            'kernel': 'corr_lookup', 'bound': 'hbm', 'achieved': round(lk, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+            'frac': round(lk / PEAK_HBM_GBS, 4), 'traffic': None, 'bytes_per_launch': bytes_['corr_lookup'],
+            'ms_per_launch': stage_ms['corr_lookup']}
+        mfma_ms = sum(stage_ms[k] for k in flops)
+        result['update_block_tflops'] = round(sum(flops.values()) / (mfma_ms * 1e-3) / 1e12, 2)
+        result['stage_ms'] = stage_ms
+        result['pre_loop_ms'] = {k: round(v, 4) for k, v in pre_ms.items()}
+        result['roofline_timing'] = 'HIP events on the launch stream, instrumented replay of the timed steps'
+
+        # ---------------- PCIe-inclusive rate (host-resident inputs), informational only
+        if world == 1:
+            h1, h2 = img1.cpu().numpy(), img2.cpu().numpy()
+            step(h1, h2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = max(1, min(args.steps, 3))
+            for _ in range(n):
+                step(h1, h2)
+            torch.cuda.synchronize()
+            result['value_incl_h2d'] = round(B * n / (time.perf_counter() - t0), 3)
+
+        # ---------------- CPU baseline: the oracle (reference restatement) on this box's host cores
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle
+            o = oracle.RAFT(wts, iters_pred=ITERS)
+            c1, c2 = img1[:1].cpu().numpy(), img2[:1].cpu().numpy()
+            oracle.RAFT(wts, iters_pred=1)([c1, c2])            # warm-up (thread pool, allocator)
+            times = []
+            for _ in range(max(1, args.cpu_runs)):
+                t0 = time.perf_counter()
+                o([c1, c2])
+                times.append(time.perf_counter() - t0)
+            result['cpu_baseline'] = {
+                'value': round(1.0 / float(np.median(times)), 4), 'unit': 'image-pairs/s',
+                'cores': torch.get_num_threads(), 'host_cpus': os.cpu_count(), 'kind': 'port',
+                'sample': f'{len(times)} x (1,{H},{W},3) pair, iters_pred={ITERS}, torch-CPU fp32 restatement '
+                          f'of the tf.keras path (oracle/), median; TensorFlow itself is not installable here'}
+        print(json.dumps(result), flush=True)
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', f'bench_n{world}.json'), 'w') as f:
+                json.dump(result, f, indent=1)
+        except OSError:
+            pass
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,216 @@
+/*
+ * raft_hip.h -- C ABI of libraft_hip.so: the MI355X (gfx950) RAFT forward-prediction hot path.
+ *
+ * Every entry point replaces one piece of the reference's Python/TensorFlow path
+ * (daigo0927/tf-raft); the reference interface each one stands in for is cited as
+ * file:line into the reference tree.  The reference has no FFI of its own (it is pure
+ * Python on TensorFlow ops), so "what its FFI for this path would bind" is exactly the set
+ * of op groups listed here; INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, explicit sizes, no torch / C++ types;
+ *   - all tensors are fp32, NHWC (channels contiguous), exactly the reference's layouts;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only
+ *     enqueue work, they never synchronise and never allocate;
+ *   - return value: RAFT_OK (0), a negative RAFT_E_* argument error, or a positive
+ *     hipError_t from the launch; no exception or abort crosses the ABI;
+ *   - the library is stateless and re-entrant (ordering only through `stream`).
+ */
+#ifndef RAFT_HIP_H_
+#define RAFT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAFT_HIP_VERSION 100          /* 0.1.0 */
+#define RAFT_MAX_LEVELS 4
+
+enum {
+    RAFT_OK = 0,
+    RAFT_E_NULL = -1,        /* a required pointer is NULL */
+    RAFT_E_SHAPE = -2,       /* a dimension is non-positive or inconsistent */
+    RAFT_E_UNSUPPORTED = -3, /* radius / channel count / kernel size not instantiated */
+    RAFT_E_ALIGN = -4        /* a pointer or leading dimension is not 16-byte aligned */
+};
+
+int raft_version(void);
+/* Human-readable message for a return code (RAFT_E_* or hipError_t). */
+const char *raft_error_string(int rc);
+
+/* ------------------------------------------------------------------ correlation volume */
+
+/* Pyramid geometry.  Level l holds, for each of the B*h*w query pixels, an (lh[l], lw[l])
+ * row-major map; lh/lw follow tf.nn.avg_pool2d(2, 2, 'VALID') (floor).  level_offsets[l] is
+ * the float offset of level l inside one allocation, level_offsets[levels] the total float
+ * count.  Host-only helper (no GPU work).  reference corr.py:106-114. */
+int raft_corr_pyramid_layout(int B, int h, int w, int levels,
+                             int64_t *level_offsets /* [levels+1] */,
+                             int *lh /* [levels] */, int *lw /* [levels] */);
+
+/* Float count of the fmap2 feature-pyramid workspace raft_corr_build_f32 needs. */
+int64_t raft_corr_build_workspace_floats(int B, int h, int w, int C, int levels);
+
+/* All-pairs correlation volume + 4-level pyramid.
+ * Replaces CorrBlock.__init__ / CorrBlock.correlation (reference corr.py:100-114, 154-162):
+ *   corr[b, q, t] = <fmap1[b, q, :], fmap2[b, t, :]> / sqrt(C), then 3x avg_pool2d over t.
+ * fmap1, fmap2: (B, h, w, C).  pyr: float[level_offsets[levels]]; level l is laid out
+ * (B*h*w, lh[l], lw[l]) row-major == the reference's corr_pyramid[l] with its trailing 1 dropped.
+ * Levels > 0 are computed as <fmap1, avgpool_l(fmap2)> / sqrt(C) (average pooling over the
+ * target dims commutes with the dot product); `workspace` holds the pooled fmap2 pyramid. */
+int raft_corr_build_f32(const float *fmap1, const float *fmap2, int B, int h, int w, int C,
+                        int levels, float *pyr, const int64_t *level_offsets,
+                        float *workspace, void *stream);
+
+/* Windowed bilinear pyramid lookup.  Replaces CorrBlock.retrieve + bilinear_sampler
+ * (reference corr.py:116-152, 28-69), including its exact semantics: clamp, ceil/floor
+ * weights (integer or out-of-range coordinate => 0), window axis 0 offsets x.
+ * coords: (B, h, w, 2) xy.  out: (B, h, w, ld_out) with channel = lvl*(2r+1)^2 + a*(2r+1) + b
+ * in the first levels*(2r+1)^2 channels; channels beyond that are left untouched.
+ * radius 3 and 4 are instantiated. */
+int raft_corr_lookup_f32(const float *pyr, const int64_t *level_offsets, const float *coords,
+                         int B, int h, int w, int levels, int radius,
+                         float *out, int ld_out, void *stream);
+
+/* Same lookup without a stored volume ("alternate" correlation; no reference code --
+ * the reference README.md:109 notes its absence): correlations of the (2r+2)^2 footprint are
+ * computed on demand from fmap1 and the pooled fmap2 pyramid held in `fmap2_pyr`
+ * (the workspace layout of raft_corr_build_f32, filled by raft_fmap_pyramid_f32). */
+int raft_fmap_pyramid_f32(const float *fmap2, int B, int h, int w, int C, int levels,
+                          float *fmap2_pyr, void *stream);
+int raft_corr_lookup_ondemand_f32(const float *fmap1, const float *fmap2_pyr,
+                                  const float *coords, int B, int h, int w, int C,
+                                  int levels, int radius, float *out, int ld_out,
+                                  void *stream);
+
+/* bilinear_sampler (reference corr.py:28-69) as a standalone op.
+ * image: (n, h, w[, 1]); coords: (n, kh, kw, 2) xy; out: (n, kh, kw[, 1]). */
+int raft_bilinear_sampler_f32(const float *image, const float *coords, int64_t n, int h, int w,
+                              int kh, int kw, float *out, void *stream);
+
+/* coords_grid (reference corr.py:72-90): coords[b, y, x] = (x, y). */
+int raft_coords_grid_f32(float *coords, int B, int h, int w, void *stream);
+
+/* ------------------------------------------------------------------ upsampling */
+
+/* RAFT.upsample_flow (reference model.py:39-66): softmax over the 9 taps of
+ * mask[b, y, x, (i*8 + j)*9 + k], 3x3 zero-padded neighbourhood of 8*flow, depth_to_space(8).
+ * flow: (B, h, w, 2); mask: (B, h, w, 576); out: (B, 8h, 8w, 2). */
+int raft_upsample_convex_f32(const float *flow, const float *mask, int B, int h, int w,
+                             float *out, void *stream);
+
+/* upflow8 (reference corr.py:93-96): 8 * tf.image.resize(flow, (8h, 8w), 'bilinear')
+ * with TF2 half-pixel centres.  flow: (B, h, w, 2); out: (B, 8h, 8w, 2). */
+int raft_upflow8_f32(const float *flow, int B, int h, int w, float *out, void *stream);
+
+/* ------------------------------------------------------------------ convolutions */
+
+/* Packed weight layout of the implicit-GEMM convolution: for a Keras kernel (kh, kw, Cin, Cout)
+ *   wp[((t * (Kpad/4) + k/4) * npad + n) * 4 + k%4] = kernel[t / kw, t % kw, k, n]
+ * with Kpad = Cin rounded up per input source to a multiple of 32 and npad = Cout rounded up
+ * to a multiple of 64; padding is zero.  bias is float[npad].  The host mirror
+ * (tf_raft_amd/packing.py) produces these once per model. */
+
+enum { RAFT_ACT_NONE = 0, RAFT_ACT_RELU = 1 };
+
+/* One stride-1 'same' Keras Conv2D (+ optional relu, + scale) on fp32 MFMA.
+ * Replaces a layers.Conv2D call (reference update.py:10-11, 91-95, 138-140).
+ * The input is the channel concatenation of up to two NHWC sources: channels [0, c0) of a0
+ * (pixel stride lda0 floats) followed by [0, c1) of a1 (c1 may be 0, a1 NULL); c0 and c1 must be
+ * multiples of 32 (pad with zero channels).  out[pixel * ldo + n] for n < nvalid.
+ * (kh, kw) in {(1,1), (3,3), (1,5), (5,1)}. */
+int raft_conv2d_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                    const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
+                    int npad, int nvalid, int act, float scale, float *out, int ldo,
+                    void *stream);
+
+/* ------------------------------------------------------------------ update block */
+
+typedef struct raft_conv_weights {
+    const float *wp;     /* packed kernel (see above) or a layer-specific layout */
+    const float *bias;
+    int npad;
+} raft_conv_weights;
+
+/* BasicUpdateBlock weights (reference update.py:128-153).  z and r convolutions of each GRU
+ * half are fused along N (npad 256 = [z | r]); flow_head.conv1 and mask[0] are fused along N
+ * (npad 512 = [flow_head.conv1 | mask.0]).
+ * convf1: (7,7,2,128) kept in Keras layout [t][c][n] (98 x 128 floats).
+ * fh2: flow_head.conv2 (3,3,256,2) kept in Keras layout [t][c][2]. */
+typedef struct raft_basic_update_weights {
+    raft_conv_weights convc1, convc2, convf1, convf2, conv;
+    raft_conv_weights gru_zr1, gru_q1, gru_zr2, gru_q2;
+    raft_conv_weights fh1_mask0, fh2, mask2;
+} raft_basic_update_weights;
+
+/* Device state of the recurrent loop (all caller-owned, (B*h*w) pixels, NHWC):
+ *   net    (M,128)  hidden state h, updated in place
+ *   x      (M,256)  GRU input [inp(128) | motion(126) | flow(2)]; inp is written once by
+ *                   raft_prepare_state_f32, the rest every iteration
+ *   corr   (M,352)  lookup output, 324 used + 28 zero pad channels
+ *   coords1(M,2), flow (M,2), delta (M,2), mask (M,576)
+ *   ws              scratch, raft_update_workspace_floats() floats */
+typedef struct raft_state {
+    float *net, *x, *corr, *coords1, *flow, *delta, *mask, *ws;
+} raft_state;
+
+int64_t raft_update_workspace_floats(int B, int h, int w);
+
+/* model.py:84-89 -- net = tanh(cnet[..., :128]); inp = relu(cnet[..., 128:]); coords1 = grid;
+ * flow = 0; zero the pad channels of corr.  cnet: (B, h, w, 256). */
+int raft_prepare_state_f32(const float *cnet, int B, int h, int w, const raft_state *st,
+                           void *stream);
+
+/* One BasicUpdateBlock call + the coordinate update (reference update.py:143-153 and
+ * model.py:97-102): reads st->corr, st->flow, st->net, st->x; writes st->net, st->mask
+ * (already scaled by 0.25), st->delta, st->coords1 (+= delta), st->flow (coords1 - coords0). */
+int raft_update_basic_f32(const raft_basic_update_weights *wts, int B, int h, int w,
+                          const raft_state *st, void *stream);
+
+/* The whole prediction loop of RAFT.call (reference model.py:91-109), `iters` times:
+ * lookup -> update -> coords1 += delta -> convex upsample.  flow_up: (iters, B, 8h, 8w, 2);
+ * prediction i is written to flow_up + i * B*8h*8w*2. */
+int raft_iterate_basic_f32(const raft_basic_update_weights *wts, const float *pyr,
+                           const int64_t *level_offsets, int B, int h, int w, int iters,
+                           const raft_state *st, float *flow_up, void *stream);
+
+/* Profiling twin of raft_iterate_basic_f32 (bench.py only): the same launches with a HIP event
+ * recorded on `stream` after every kernel; synchronises the stream and accumulates the elapsed
+ * milliseconds of each stage over all iterations into the HOST array stage_ms.  Stage order:
+ * lookup, convc1, convc2, convf1, convf2, conv, gru_zr1, gru_q1, gru_zr2, gru_q2, fh1_mask0, fh2,
+ * mask2, upsample. */
+#define RAFT_BASIC_STAGES 14
+int raft_iterate_basic_timed_f32(const raft_basic_update_weights *wts, const float *pyr,
+                                 const int64_t *level_offsets, int B, int h, int w, int iters,
+                                 const raft_state *st, float *flow_up, void *stream,
+                                 float *stage_ms /* host, [RAFT_BASIC_STAGES] */);
+
+/* ------------------------------------------------------------------ SmallRAFT update block */
+
+/* SmallUpdateBlock weights (reference update.py:109-125): z and r of the 3x3 ConvGRU fused along N
+ * (npad 192 = [z 96 | r 96]); convf1 (7,7,2,64) and fh2 = flow_head.conv2 (3,3,128,2) in Keras layout.
+ * State: net (M,96); x (M,160) = [inp 64 | motion 80 | flow 2 | 14 zero pad]; corr (M,224) = 196 used
+ * + 28 zero pad; mask is unused (SmallUpdateBlock returns None). */
+typedef struct raft_small_update_weights {
+    raft_conv_weights convc1, convf1, convf2, conv, gru_zr, gru_q, fh1, fh2;
+} raft_small_update_weights;
+
+int64_t raft_small_update_workspace_floats(int B, int h, int w);
+/* cnet: (B, h, w, 160) -> net = tanh(cnet[..., :96]), inp = relu(cnet[..., 96:]).  model.py:206-211 */
+int raft_prepare_state_small_f32(const float *cnet, int B, int h, int w, const raft_state *st,
+                                 void *stream);
+/* One SmallUpdateBlock call + coordinate update (update.py:118-125, model.py:216-220). */
+int raft_update_small_f32(const raft_small_update_weights *wts, int B, int h, int w,
+                          const raft_state *st, void *stream);
+/* The prediction loop of SmallRAFT.call (model.py:213-226): lookup (radius 3) -> update -> upflow8. */
+int raft_iterate_small_f32(const raft_small_update_weights *wts, const float *pyr,
+                           const int64_t *level_offsets, int B, int h, int w, int iters,
+                           const raft_state *st, float *flow_up, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFT_HIP_H_ */

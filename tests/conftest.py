@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:   # noqa: BLE001
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason='no GPU visible')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture
+def rng():
+    return np.random.default_rng(1234)
+
+
+def report(name, **vals):
+    """Print measured errors so that `pytest -rA` / `-s` logs carry the numbers, not just PASS."""
+    print('[parity] ' + name + ' ' + ' '.join(f'{k}={v:.3e}' if isinstance(v, float) else f'{k}={v}'
+                                             for k, v in vals.items()))

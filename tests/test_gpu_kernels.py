@@ -1,0 +1,326 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against the CPU oracle.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.as_tensor(np.asarray(a))
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_library_is_native_and_loaded():
+    from tf_raft_amd import _ffi
+    lib = _ffi.load_library()
+    assert lib.raft_version() == 100
+    with open('/proc/self/maps') as f:
+        assert 'libraft_hip.so' in f.read()
+
+
+def test_coords_grid():
+    import oracle
+    from tf_raft_amd.layers.corr import coords_grid
+    got = _np(coords_grid(3, 7, 12))
+    ref = oracle.coords_grid(3, 7, 12).numpy()
+    np.testing.assert_array_equal(got, ref)
+    assert got[0, 2, 5, 0] == 5 and got[0, 2, 5, 1] == 2      # [..., 0] = x, [..., 1] = y
+
+
+def test_bilinear_sampler_interior_matches_oracle_and_grid_sample(rng):
+    """reference tests/layers/test_corr.py:15-27 (sampler == resampler for interior coordinates)."""
+    import oracle
+    from tf_raft_amd.layers.corr import bilinear_sampler
+    n, h, w, r = 4 * 32 * 32, 32, 32, 4
+    image = rng.normal(size=(n, h, w, 1)).astype(np.float32)
+    cx = rng.uniform(0, w - 1, size=(n, 2 * r + 1, 2 * r + 1)).astype(np.float32)
+    cy = rng.uniform(0, h - 1, size=(n, 2 * r + 1, 2 * r + 1)).astype(np.float32)
+    coords = np.stack([cx, cy], axis=-1)
+    got = _np(bilinear_sampler(image, coords))
+    ref = oracle.bilinear_sampler(_t(image), _t(coords)).numpy()
+    report('bilinear_sampler', max_abs=float(np.abs(got - ref).max()))
+    np.testing.assert_array_equal(got, ref)                    # same unfused arithmetic: bit-exact
+    # independent comparator standing in for tfa.image.resampler
+    grid = torch.stack([_t(cx) / (w - 1) * 2 - 1, _t(cy) / (h - 1) * 2 - 1], dim=-1)
+    gs = torch.nn.functional.grid_sample(_t(image).permute(0, 3, 1, 2), grid, mode='bilinear',
+                                         padding_mode='zeros', align_corners=True)
+    np.testing.assert_allclose(got[..., 0], gs[:, 0].numpy(), atol=1e-5, rtol=1e-5)
+
+
+def test_bilinear_sampler_integer_and_out_of_range_are_zero(rng):
+    """ceil/floor weights vanish on integer coordinates; clamped samples are integer."""
+    import oracle
+    from tf_raft_amd.layers.corr import bilinear_sampler
+    n, h, w = 6, 5, 7
+    image = rng.normal(size=(n, h, w, 1)).astype(np.float32) + 3.0
+    coords = np.zeros((n, 3, 4, 2), np.float32)
+    coords[..., 0] = rng.uniform(0.1, w - 1.1, size=(n, 3, 4))
+    coords[..., 1] = rng.uniform(0.1, h - 1.1, size=(n, 3, 4))
+    coords[0, :, :, 0] = 2.0            # integer x
+    coords[1, :, :, 1] = 3.0            # integer y
+    coords[2, :, :, 0] = -0.75          # out of range (left)
+    coords[3, :, :, 0] = w - 1 + 0.25   # out of range (right)
+    coords[4, :, :, 1] = h + 10.0       # out of range (bottom)
+    got = _np(bilinear_sampler(image, coords))
+    ref = oracle.bilinear_sampler(_t(image), _t(coords)).numpy()
+    np.testing.assert_array_equal(got, ref)
+    assert np.all(got[:5] == 0.0)
+    assert np.all(got[5] != 0.0)
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 12, 256), (1, 56, 64, 256), (2, 9, 13, 128)])
+def test_corr_build_matches_oracle_pyramid(rng, shape):
+    import oracle
+    from tf_raft_amd.layers.corr import CorrBlock
+    B, h, w, C = shape
+    levels = 4 if min(h, w) >= 8 else 3
+    f1 = rng.normal(size=shape).astype(np.float32)
+    f2 = rng.normal(size=shape).astype(np.float32)
+    dev = CorrBlock(f1, f2, num_levels=levels, radius=4)
+    ref = oracle.CorrBlock(_t(f1), _t(f2), num_levels=levels, radius=4)
+    ref64 = oracle.CorrBlock(_t(f1).double(), _t(f2).double(), num_levels=levels, radius=4)
+    for l, (g, r, r64) in enumerate(zip(dev.corr_pyramid, ref.corr_pyramid, ref64.corr_pyramid)):
+        g = _np(g)
+        assert g.shape == tuple(r.shape)
+        err = float(np.abs(g - r64.numpy()).max())
+        err_ref = float(np.abs(r.numpy() - r64.numpy()).max())
+        report(f'corr_build{shape} L{l}', max_abs_vs_f64=err, oracle32_vs_f64=err_ref)
+        assert err <= max(4 * err_ref, 2e-5)
+
+
+def _device_corr_with_oracle_pyramid(f1, f2, levels, radius):
+    """Device CorrBlock whose volume is overwritten with the oracle's values, so the lookup can be
+    compared in isolation (bit-exact arithmetic expected)."""
+    import oracle
+    from tf_raft_amd.layers.corr import CorrBlock
+    dev = CorrBlock(f1, f2, num_levels=levels, radius=radius)
+    ref = oracle.CorrBlock(_t(f1), _t(f2), num_levels=levels, radius=radius)
+    for l in range(levels):
+        n = ref.corr_pyramid[l].numel()
+        dev._pyr[dev._off[l]:dev._off[l] + n].copy_(ref.corr_pyramid[l].reshape(-1).to(dev._pyr.device))
+    return dev, ref
+
+
+@pytest.mark.parametrize('radius,shape', [(4, (2, 8, 12, 64)), (3, (1, 16, 24, 32)), (4, (1, 56, 64, 32))])
+def test_corr_lookup_bit_exact_vs_oracle(rng, radius, shape):
+    B, h, w, C = shape
+    f1 = rng.normal(size=shape).astype(np.float32)
+    f2 = rng.normal(size=shape).astype(np.float32)
+    dev, ref = _device_corr_with_oracle_pyramid(f1, f2, 4, radius)
+    import oracle
+    grid = oracle.coords_grid(B, h, w).numpy()
+    cases = {
+        'iteration0_integer_grid': grid,
+        'random_flow': grid + rng.normal(scale=3.0, size=grid.shape).astype(np.float32),
+        'large_flow_out_of_range': grid + rng.normal(scale=40.0, size=grid.shape).astype(np.float32),
+        'half_integer': grid + 0.5,
+        'near_border': np.clip(grid + rng.normal(scale=0.01, size=grid.shape), -1, None).astype(np.float32),
+    }
+    for name, coords in cases.items():
+        got = _np(dev.retrieve(coords))
+        want = ref.retrieve(_t(coords)).numpy()
+        assert got.shape == want.shape == (B, h, w, 4 * (2 * radius + 1) ** 2)
+        report(f'corr_lookup r={radius} {name}', max_abs=float(np.abs(got - want).max()),
+               nonzero=float((want != 0).mean()))
+        np.testing.assert_array_equal(got, want)
+    # on the integer grid the level-0 window is identically zero
+    got0 = _np(dev.retrieve(grid))
+    assert np.all(got0[..., :(2 * radius + 1) ** 2] == 0.0)
+
+
+def test_corr_lookup_axis_quirk(rng):
+    """window axis 0 (index a) offsets x, axis 1 (index b) offsets y."""
+    B, h, w, C, r = 1, 16, 16, 32, 4
+    f1 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    f2 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    dev, ref = _device_corr_with_oracle_pyramid(f1, f2, 4, r)
+    import oracle
+    coords = oracle.coords_grid(B, h, w).numpy() + np.float32(0.25)
+    got = _np(dev.retrieve(coords))
+    q = 8 * w + 8                                   # query pixel (y=8, x=8)
+    img = ref.corr_pyramid[0][q, :, :, 0].numpy()
+    a, b = 6, 1                                     # x offset +2, y offset -3
+    sx, sy = 8.25 + (a - r), 8.25 + (b - r)
+    x0, y0 = int(np.floor(sx)), int(np.floor(sy))
+    want = ((1 - (sy - y0)) * (1 - (sx - x0)) * img[y0, x0] + (1 - (sy - y0)) * (sx - x0) * img[y0, x0 + 1]
+            + (sy - y0) * (1 - (sx - x0)) * img[y0 + 1, x0] + (sy - y0) * (sx - x0) * img[y0 + 1, x0 + 1])
+    assert abs(got[0, 8, 8, a * 9 + b] - want) < 1e-5
+
+
+@pytest.mark.parametrize('radius,C', [(4, 256), (3, 128)])
+def test_corr_lookup_ondemand_matches_volume(rng, radius, C):
+    from tf_raft_amd.layers.corr import CorrBlock
+    B, h, w = 2, 16, 24
+    f1 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    f2 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    vol = CorrBlock(f1, f2, 4, radius)
+    alt = CorrBlock(f1, f2, 4, radius, alternate=True)
+    import oracle
+    coords = oracle.coords_grid(B, h, w).numpy() + rng.normal(scale=4.0, size=(B, h, w, 2)).astype(np.float32)
+    a, b = _np(vol.retrieve(coords)), _np(alt.retrieve(coords))
+    report(f'ondemand r={radius} C={C}', max_abs=float(np.abs(a - b).max()), scale=float(np.abs(a).max()))
+    np.testing.assert_allclose(b, a, atol=2e-5 * max(1.0, float(np.abs(a).max())), rtol=0)
+    with pytest.raises(AttributeError):
+        alt.corr_pyramid
+
+
+def test_upsample_convex_matches_oracle(rng):
+    from oracle.model import upsample_flow
+    from tf_raft_amd import RAFT
+    B, h, w = 2, 7, 9
+    flow = rng.normal(scale=5.0, size=(B, h, w, 2)).astype(np.float32)
+    mask = rng.normal(scale=2.0, size=(B, h, w, 576)).astype(np.float32)
+    want = upsample_flow(_t(flow), _t(mask)).numpy()
+    got = _np(RAFT.upsample_flow(None, flow, mask))
+    assert got.shape == (B, 8 * h, 8 * w, 2)
+    report('upsample_convex', max_abs=float(np.abs(got - want).max()))
+    np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
+
+
+def test_upflow8_matches_oracle_and_torch(rng):
+    import oracle
+    from tf_raft_amd.layers.corr import upflow8
+    flow = rng.normal(scale=5.0, size=(2, 6, 11, 2)).astype(np.float32)
+    got = _np(upflow8(flow))
+    want = oracle.upflow8(_t(flow)).numpy()
+    report('upflow8', max_abs=float(np.abs(got - want).max()))
+    np.testing.assert_allclose(got, want, atol=1e-5, rtol=1e-6)
+    ti = 8 * torch.nn.functional.interpolate(_t(flow).permute(0, 3, 1, 2), scale_factor=8, mode='bilinear',
+                                             align_corners=False).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(got, ti, atol=1e-4, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+def _conv_device(x_srcs, kernel, bias, act, scale=1.0, nvalid=None):
+    """Run raft_conv2d_f32 on NHWC sources [(array, c_pad), ...]."""
+    from tf_raft_amd import _dev, packing
+    from tf_raft_amd._ffi import check
+    kh, kw, cin, cout = kernel.shape
+    srcs = []
+    for arr, cpad in x_srcs:
+        B, H, W, c = arr.shape
+        buf = np.zeros((B, H, W, cpad), np.float32)
+        buf[..., :c] = arr
+        srcs.append(_dev.to_device(buf))
+    wp, b, npad = packing.pack_conv(kernel, bias, [(a.shape[-1], cp) for a, cp in x_srcs])
+    wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
+    nvalid = nvalid or cout
+    out = torch.full((B, H, W, nvalid), float('nan'), device=srcs[0].device)
+    a1 = srcs[1] if len(srcs) > 1 else None
+    check(_dev.lib().raft_conv2d_f32(_dev.ptr(srcs[0]), srcs[0].shape[-1], srcs[0].shape[-1],
+                                     _dev.ptr(a1) if a1 is not None else None,
+                                     a1.shape[-1] if a1 is not None else 0, a1.shape[-1] if a1 is not None else 0,
+                                     _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw, npad, nvalid, act, scale,
+                                     _dev.ptr(out), nvalid, _dev.stream_ptr()), 'conv2d')
+    torch.cuda.synchronize()
+    return _np(out)
+
+
+@pytest.mark.parametrize('tile', ['128128', '064128', '128064', '064064'])
+@pytest.mark.parametrize('ksize', [(1, 1), (3, 3), (1, 5), (5, 1)])
+def test_conv2d_mfma_matches_oracle(rng, ksize, tile):
+    from oracle import tf_ops
+    kh, kw = ksize
+    B, H, W = 2, 9, 13                      # M = 234: exercises the M tail of every tile
+    c_a, c_b, cout = 40, 64, 150            # two sources, first one padded 40 -> 64; N tail 150 -> 192
+    xa = rng.normal(size=(B, H, W, c_a)).astype(np.float32)
+    xb = rng.normal(size=(B, H, W, c_b)).astype(np.float32)
+    kernel = (rng.normal(size=(kh, kw, c_a + c_b, cout)) * 0.1).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    os.environ['RAFT_CONV_TILE'] = tile
+    try:
+        got = _conv_device([(xa, 64), (xb, 64)], kernel, bias, act=1, scale=0.5)
+    finally:
+        os.environ.pop('RAFT_CONV_TILE', None)
+    x = torch.cat([_t(xa), _t(xb)], dim=-1)
+    want = 0.5 * torch.relu(tf_ops.conv2d(x.double(), _t(kernel).double(), _t(bias).double())).numpy()
+    err = float(np.abs(got - want).max())
+    report(f'conv2d {ksize} tile {tile}', max_abs_vs_f64=err)
+    assert not np.isnan(got).any()
+    assert err < 2e-5
+
+
+def test_conv2d_rejects_bad_arguments():
+    from tf_raft_amd import _dev
+    lib = _dev.lib()
+    x = torch.zeros((1, 4, 4, 32), device='cuda')
+    w = torch.zeros((9 * 8 * 64 * 4,), device='cuda')
+    b = torch.zeros((64,), device='cuda')
+    o = torch.zeros((1, 4, 4, 64), device='cuda')
+    args = lambda **kw: [kw.get('a0', _dev.ptr(x)), 32, kw.get('c0', 32), None, 0, 0, _dev.ptr(w), _dev.ptr(b),   # noqa: E731
+                         1, 4, 4, kw.get('kh', 3), 3, 64, 64, 0, 1.0, _dev.ptr(o), 64, None]
+    assert lib.raft_conv2d_f32(*args()) == 0
+    assert lib.raft_conv2d_f32(*args(a0=None)) == -1          # RAFT_E_NULL
+    assert lib.raft_conv2d_f32(*args(c0=20)) == -3            # RAFT_E_UNSUPPORTED (not a multiple of 32)
+    assert lib.raft_conv2d_f32(*args(kh=7)) == -3             # kernel size not instantiated
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------
+def _update_inputs(rng, variant, B, h, w):
+    from tf_raft_amd.layers.update import _GEOM
+    g = _GEOM[variant]
+    net = np.tanh(rng.normal(size=(B, h, w, g['hdim']))).astype(np.float32)
+    inp = np.maximum(rng.normal(size=(B, h, w, g['cdim'])), 0).astype(np.float32)
+    corr = rng.normal(size=(B, h, w, g['corr_used'])).astype(np.float32)
+    flow = rng.normal(scale=3.0, size=(B, h, w, 2)).astype(np.float32)
+    return net, inp, corr, flow
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 12), (1, 56, 64)])
+def test_basic_update_block_matches_oracle(rng, shape):
+    from oracle.layers import W, basic_update_block
+    from tf_raft_amd import weights as wm
+    from tf_raft_amd.layers.update import BasicUpdateBlock
+    B, h, w = shape
+    wts = wm.init_weights('raft', seed=3, perturb=True)
+    net, inp, corr, flow = _update_inputs(rng, 'raft', B, h, w)
+    blk = BasicUpdateBlock(filters=128, weights=wts)
+    gn, gm, gd = blk([net, inp, corr, flow])
+    W64 = W(wts, torch.float64)
+    rn, rm, rd = basic_update_block(W64, 'update_block', *[_t(a).double() for a in (net, inp, corr, flow)])
+    W32 = W(wts, torch.float32)
+    on, om, od = basic_update_block(W32, 'update_block', *[_t(a) for a in (net, inp, corr, flow)])
+    for name, g, r, o, tol in (('net', gn, rn, on, 2e-5), ('mask', gm, rm, om, 5e-5), ('delta', gd, rd, od, 5e-5)):
+        err = float(np.abs(_np(g) - r.numpy()).max())
+        err_o = float(np.abs(o.numpy() - r.numpy()).max())
+        report(f'basic_update{shape} {name}', hip_vs_f64=err, oracle32_vs_f64=err_o)
+        assert err < max(tol, 4 * err_o)
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 12), (1, 32, 32)])
+def test_small_update_block_matches_oracle(rng, shape):
+    from oracle.layers import W, small_update_block
+    from tf_raft_amd import weights as wm
+    from tf_raft_amd.layers.update import SmallUpdateBlock
+    B, h, w = shape
+    wts = wm.init_weights('small', seed=4, perturb=True)
+    net, inp, corr, flow = _update_inputs(rng, 'small', B, h, w)
+    blk = SmallUpdateBlock(filters=96, weights=wts)
+    gn, gm, gd = blk([net, inp, corr, flow])
+    assert gm is None
+    W64 = W(wts, torch.float64)
+    rn, _, rd = small_update_block(W64, 'update_block', *[_t(a).double() for a in (net, inp, corr, flow)])
+    for name, g, r, tol in (('net', gn, rn, 2e-5), ('delta', gd, rd, 5e-5)):
+        err = float(np.abs(_np(g) - r.numpy()).max())
+        report(f'small_update{shape} {name}', hip_vs_f64=err)
+        assert err < tol
+
+
+def test_update_block_rejects_wrong_shapes(rng):
+    from tf_raft_amd.layers.update import BasicUpdateBlock
+    blk = BasicUpdateBlock(filters=128)
+    net, inp, corr, flow = _update_inputs(rng, 'raft', 1, 8, 8)
+    with pytest.raises(ValueError):
+        blk([net, inp, corr[..., :100], flow])
+    with pytest.raises(ValueError):
+        BasicUpdateBlock(filters=64)

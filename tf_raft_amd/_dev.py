@@ -1,0 +1,59 @@
+"""Device-memory plumbing: PyTorch-ROCm tensors own HBM buffers and provide the HIP stream;
+all compute on the hot path goes through ``libraft_hip.so`` (``_ffi``)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError('tf_raft_amd needs a ROCm GPU (MI355X / gfx950): no device is visible and '
+                           'there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class DeviceTensor(torch.Tensor):
+    """A device tensor that also answers ``.numpy()`` / ``np.asarray`` like the TF eager tensors
+    the reference returns (reference model.py:109), by copying to the host first."""
+
+    def numpy(self):   # type: ignore[override]
+        return self.detach().as_subclass(torch.Tensor).cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):   # noqa: D105
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+
+def wrap(t: torch.Tensor) -> torch.Tensor:
+    return t.as_subclass(DeviceTensor)
+
+
+def to_device(x, device=None, dtype=torch.float32) -> torch.Tensor:
+    """numpy / torch (any device) -> contiguous device tensor of ``dtype``."""
+    device = device or require_gpu()
+    if isinstance(x, torch.Tensor):
+        t = x.detach().as_subclass(torch.Tensor)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+def ptr(t: torch.Tensor) -> int:
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def i64_array(values):
+    return (C.c_int64 * len(values))(*values)
+
+
+def lib():
+    return _ffi.load_library()

@@ -1,0 +1,114 @@
+"""ctypes binding of ``libraft_hip.so`` (C ABI: include/raft_hip.h).
+
+There is no CPU fallback: if the shared library cannot be loaded (and cannot be built
+because hipcc is absent) importing the device path raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_LOCK = threading.Lock()
+_LIB = None
+
+c_float_p = C.c_void_p      # raw device pointers travel as void*
+c_i64_p = C.POINTER(C.c_int64)
+c_int_p = C.POINTER(C.c_int)
+
+
+class ConvWeights(C.Structure):
+    _fields_ = [('wp', C.c_void_p), ('bias', C.c_void_p), ('npad', C.c_int)]
+
+
+class BasicUpdateWeights(C.Structure):
+    _fields_ = [(n, ConvWeights) for n in (
+        'convc1', 'convc2', 'convf1', 'convf2', 'conv',
+        'gru_zr1', 'gru_q1', 'gru_zr2', 'gru_q2',
+        'fh1_mask0', 'fh2', 'mask2')]
+
+
+class SmallUpdateWeights(C.Structure):
+    _fields_ = [(n, ConvWeights) for n in (
+        'convc1', 'convf1', 'convf2', 'conv', 'gru_zr', 'gru_q', 'fh1', 'fh2')]
+
+
+class State(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'net', 'x', 'corr', 'coords1', 'flow', 'delta', 'mask', 'ws')]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_SIGNATURES = {
+    'raft_version': (C.c_int, []),
+    'raft_error_string': (C.c_char_p, [_I]),
+    'raft_corr_pyramid_layout': (_I, [_I, _I, _I, _I, c_i64_p, c_int_p, c_int_p]),
+    'raft_corr_build_workspace_floats': (C.c_int64, [_I, _I, _I, _I, _I]),
+    'raft_corr_build_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, c_i64_p, _P, _P]),
+    'raft_corr_lookup_f32': (_I, [_P, c_i64_p, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    'raft_fmap_pyramid_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    'raft_corr_lookup_ondemand_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    'raft_bilinear_sampler_f32': (_I, [_P, _P, C.c_int64, _I, _I, _I, _I, _P, _P]),
+    'raft_coords_grid_f32': (_I, [_P, _I, _I, _I, _P]),
+    'raft_upsample_convex_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    'raft_upflow8_f32': (_I, [_P, _I, _I, _I, _P, _P]),
+    'raft_conv2d_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I,
+                             C.c_float, _P, _I, _P]),
+    'raft_update_workspace_floats': (C.c_int64, [_I, _I, _I]),
+    'raft_prepare_state_f32': (_I, [_P, _I, _I, _I, C.POINTER(State), _P]),
+    'raft_update_basic_f32': (_I, [C.POINTER(BasicUpdateWeights), _I, _I, _I, C.POINTER(State), _P]),
+    'raft_iterate_basic_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
+                                    C.POINTER(State), _P, _P]),
+    'raft_iterate_basic_timed_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
+                                          C.POINTER(State), _P, _P, C.POINTER(C.c_float)]),
+    'raft_small_update_workspace_floats': (C.c_int64, [_I, _I, _I]),
+    'raft_prepare_state_small_f32': (_I, [_P, _I, _I, _I, C.POINTER(State), _P]),
+    'raft_update_small_f32': (_I, [C.POINTER(SmallUpdateWeights), _I, _I, _I, C.POINTER(State), _P]),
+    'raft_iterate_small_f32': (_I, [C.POINTER(SmallUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
+                                    C.POINTER(State), _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libraft_hip.so')
+
+
+def load_library():
+    """Load (building first if the .so is absent and hipcc is available) and type the library."""
+    global _LIB
+    with _LOCK:
+        if _LIB is not None:
+            return _LIB
+        path = library_path()
+        if not os.path.exists(path):
+            from . import build as _build
+            try:
+                _build.build_library(verbose=False)
+            except Exception as exc:   # noqa: BLE001
+                raise RuntimeError(
+                    f'libraft_hip.so is missing at {path} and could not be built ({exc}); '
+                    'the RAFT device path has no CPU fallback') from exc
+        try:
+            lib = C.CDLL(path)
+        except OSError as exc:
+            raise RuntimeError(f'cannot load {path}: {exc}; the RAFT device path has no CPU fallback') from exc
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError => symbol missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+        return lib
+
+
+def check(rc: int, what: str = '') -> None:
+    """Raise on a nonzero return code: ValueError for argument errors, RuntimeError for HIP errors."""
+    if rc == 0:
+        return
+    msg = load_library().raft_error_string(rc).decode()
+    text = f'{what}: {msg} (rc={rc})' if what else f'{msg} (rc={rc})'
+    if rc < 0:
+        raise ValueError(text)
+    raise RuntimeError(text)

@@ -1,0 +1,76 @@
+"""Builds ``libraft_hip.so`` (gfx950) in-tree with hipcc.
+
+``python -m tf_raft_amd.build`` or ``tf_raft_amd.build.build_library()``.
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only container; the
+resulting ``tf_raft_amd/lib/libraft_hip.so`` travels to the GPU box with the snapshot.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIBPATH = os.path.join(LIBDIR, 'libraft_hip.so')
+SOURCES = ['corr.hip', 'upsample.hip', 'conv.hip', 'ondemand.hip']
+HEADERS = ['common.h', 'conv_mfma.h', 'lookup_common.h', os.path.join('..', '..', 'include', 'raft_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on',
+         '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found: cannot build libraft_hip.so')
+    return exe
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    h.update(' '.join(FLAGS).encode())
+    for p in paths:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build_library(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    stamp = os.path.join(LIBDIR, 'build.sha256')
+    digest = _digest(srcs + hdrs)
+    if not force and os.path.exists(LIBPATH) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return LIBPATH
+    hipcc = _hipcc()
+    objs = []
+
+    def compile_one(src):
+        obj = os.path.join(LIBDIR, os.path.basename(src) + '.o')
+        cmd = [hipcc, *FLAGS, '-x', 'hip', '-c', src, '-o', obj]
+        if verbose:
+            print('[build]', ' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIBPATH]
+    if verbose:
+        print('[build]', ' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(stamp, 'w') as f:
+        f.write(digest)
+    return LIBPATH
+
+
+if __name__ == '__main__':
+    build_library(force='--force' in sys.argv)
+    print(LIBPATH)

@@ -1,0 +1,588 @@
+// Convolution launchers, the two small special convolutions, and the BasicUpdateBlock sequencing
+// (reference tf_raft/layers/update.py:5-153, tf_raft/model.py:84-109) for gfx950.
+#include <stdlib.h>
+
+#include "conv_mfma.h"
+
+// ------------------------------------------------------------------------------------------------
+// tile selection + dispatch of the implicit-GEMM kernel
+// ------------------------------------------------------------------------------------------------
+template <int KH, int KW, int EPI>
+static int launch_conv_tiles(const ConvArgs &a, int bm, int bn, hipStream_t s) {
+    const int64_t M = (int64_t)a.B * a.H * a.W;
+    const int grid = raft_ceil_div(M, bm) * (a.npad / bn);
+    if (bm == 128 && bn == 128)
+        conv_mfma_kernel<KH, KW, 128, 128, EPI><<<grid, 256, 0, s>>>(a);
+    else if (bm == 64 && bn == 128)
+        conv_mfma_kernel<KH, KW, 64, 128, EPI><<<grid, 256, 0, s>>>(a);
+    else if (bm == 128 && bn == 64)
+        conv_mfma_kernel<KH, KW, 128, 64, EPI><<<grid, 256, 0, s>>>(a);
+    else
+        conv_mfma_kernel<KH, KW, 64, 64, EPI><<<grid, 256, 0, s>>>(a);
+    return raft_launch_status();
+}
+
+template <int KH, int KW>
+static int launch_conv_epi(const ConvArgs &a, int epi, int bm, int bn, hipStream_t s) {
+    switch (epi) {
+        case EPI_LINEAR: return launch_conv_tiles<KH, KW, EPI_LINEAR>(a, bm, bn, s);
+        case EPI_RELU: return launch_conv_tiles<KH, KW, EPI_RELU>(a, bm, bn, s);
+        case EPI_GRU_ZR: return launch_conv_tiles<KH, KW, EPI_GRU_ZR>(a, bm, bn, s);
+        case EPI_GRU_Q: return launch_conv_tiles<KH, KW, EPI_GRU_Q>(a, bm, bn, s);
+    }
+    return RAFT_E_UNSUPPORTED;
+}
+
+// Pick the output tile that minimises (workgroups per CU, rounded up) x (tile cost).  MI355X has
+// 256 CUs; smaller tiles balance better but stage more bytes per MFMA (cost factors below are the
+// measured relative per-MAC costs).
+static void pick_tile(int64_t M, int npad, int *bm, int *bn) {
+    const char *env = getenv("RAFT_CONV_TILE");   // tuning / test override, e.g. 128064 = BM 128, BN 64
+    const int forced = env ? atoi(env) : 0;
+    if (forced) {
+        int fbm = forced / 1000, fbn = forced % 1000;
+        if ((fbm == 64 || fbm == 128) && (fbn == 64 || fbn == 128) && npad % fbn == 0) {
+            *bm = fbm;
+            *bn = fbn;
+            return;
+        }
+    }
+    const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+    const double cost[4] = {1.00, 1.06, 1.06, 1.14};
+    double best = 1e30;
+    for (int i = 0; i < 4; ++i) {
+        const int cbm = cand[i][0], cbn = cand[i][1];
+        if (npad % cbn) continue;
+        const int64_t blocks = ((M + cbm - 1) / cbm) * (npad / cbn);
+        const double t = (double)((blocks + 255) / 256) * cbm * cbn * cost[i];
+        if (t < best) {
+            best = t;
+            *bm = cbm;
+            *bn = cbn;
+        }
+    }
+}
+
+int raft_launch_conv(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s) {
+    if (a.c0 <= 0 || a.c0 % 32 || a.c1 < 0 || a.c1 % 32 || a.npad <= 0 || a.npad % 64) return RAFT_E_UNSUPPORTED;
+    if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
+    if (!raft_aligned16(a.a0) || !raft_aligned16(a.wp) || (a.c1 && !raft_aligned16(a.a1))) return RAFT_E_ALIGN;
+    int bm = 64, bn = 64;
+    pick_tile((int64_t)a.B * a.H * a.W, a.npad, &bm, &bn);
+    if (kh == 1 && kw == 1) return launch_conv_epi<1, 1>(a, epi, bm, bn, s);
+    if (kh == 3 && kw == 3) return launch_conv_epi<3, 3>(a, epi, bm, bn, s);
+    if (kh == 1 && kw == 5) return launch_conv_epi<1, 5>(a, epi, bm, bn, s);
+    if (kh == 5 && kw == 1) return launch_conv_epi<5, 1>(a, epi, bm, bn, s);
+    return RAFT_E_UNSUPPORTED;
+}
+
+extern "C" int raft_conv2d_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                               const float *wp, const float *bias, int B, int H, int W, int kh, int kw, int npad,
+                               int nvalid, int act, float scale, float *out, int ldo, void *stream) {
+    RAFT_REQUIRE_PTR(a0);
+    RAFT_REQUIRE_PTR(wp);
+    RAFT_REQUIRE_PTR(bias);
+    RAFT_REQUIRE_PTR(out);
+    RAFT_REQUIRE(c1 == 0 || a1 != nullptr, RAFT_E_NULL);
+    RAFT_REQUIRE(B > 0 && H > 0 && W > 0 && nvalid > 0 && nvalid <= npad && ldo >= nvalid, RAFT_E_SHAPE);
+    RAFT_REQUIRE(lda0 >= c0 && (c1 == 0 || lda1 >= c1), RAFT_E_SHAPE);
+    RAFT_REQUIRE(act == RAFT_ACT_NONE || act == RAFT_ACT_RELU, RAFT_E_UNSUPPORTED);
+    ConvArgs a = {};
+    a.a0 = a0; a.a1 = a1; a.lda0 = lda0; a.lda1 = lda1; a.c0 = c0; a.c1 = c1;
+    a.wp = wp; a.bias = bias; a.B = B; a.H = H; a.W = W;
+    a.npad = npad; a.nvalid = nvalid; a.hid = 0; a.scale = scale;
+    a.o0 = out; a.ldo0 = ldo;
+    return raft_launch_conv(a, kh, kw, act == RAFT_ACT_RELU ? EPI_RELU : EPI_LINEAR, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// convf1: 7x7, Cin = 2 (flow), relu.  K = 98 is too thin for the MFMA path and the work is 0.4 %
+// of the block, so: lane = output channel with its 98 weights held in registers, the flow halo
+// tile lives in LDS and is read as wave-uniform (broadcast) ds_read_b64.  [reference update.py:93]
+// ------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ void __launch_bounds__(256) conv7x7_c2_kernel(const float *__restrict__ flow, const float *__restrict__ wk,
+                                                         const float *__restrict__ bias, int B, int H, int W,
+                                                         float *__restrict__ out, int ldo) {
+    constexpr int TP = 32;               // pixels (along x) per workgroup
+    constexpr int CG = COUT / 64;        // channel groups of 64 lanes
+    constexpr int PG = 4 / CG;           // pixel groups
+    static_assert(COUT == 64 || COUT == 128, "conv7x7_c2: COUT must be 64 or 128");
+    __shared__ float2 sf[7][TP + 6];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int xt = (W + TP - 1) / TP;
+    const int x0 = (blockIdx.x % xt) * TP;
+    const int y = (blockIdx.x / xt) % H;
+    const int b = blockIdx.x / (xt * H);
+    for (int i = tid; i < 7 * (TP + 6); i += 256) {
+        const int r = i / (TP + 6), c = i - r * (TP + 6);
+        const int yy = y + r - 3, xx = x0 + c - 3;
+        float2 v = make_float2(0.f, 0.f);
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = ((const float2 *)flow)[((int64_t)b * H + yy) * W + xx];
+        sf[r][c] = v;
+    }
+    const int cg = wid % CG, pg = wid / CG;
+    const int n = cg * 64 + lane;
+    float wr[98];
+#pragma unroll
+    for (int k = 0; k < 98; ++k) wr[k] = wk[k * COUT + n];
+    const float bv = bias[n];
+    __syncthreads();
+    constexpr int PPW = TP / PG;         // pixels per wave
+    for (int i = 0; i < PPW; ++i) {
+        const int xl = pg * PPW + i;
+        const int x = x0 + xl;
+        if (x >= W) break;
+        float acc = bv;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const float2 f = sf[ky][xl + kx];
+                acc = fmaf(f.x, wr[(ky * 7 + kx) * 2], acc);
+                acc = fmaf(f.y, wr[(ky * 7 + kx) * 2 + 1], acc);
+            }
+        out[(((int64_t)b * H + y) * W + x) * ldo + n] = fmaxf(acc, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// flow_head.conv2: 3x3, Cout = 2, fused with the coordinate update of the loop
+//   delta = conv(x) + b; coords1 += delta; flow = coords1 - coords0    [update.py:14, model.py:97-102]
+// One wavefront per pixel: lanes split the CIN channels (float4 / float2 per lane), per-lane partial
+// dot products for the 2 outputs, then a wave-wide butterfly reduction.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int CIN>
+__global__ void __launch_bounds__(256) flowhead2_kernel(const float *__restrict__ x, int ldx,
+                                                        const float *__restrict__ wk,   // [9][CIN][2]
+                                                        const float *__restrict__ bias, int B, int H, int W,
+                                                        float *__restrict__ delta, float *__restrict__ coords1,
+                                                        float *__restrict__ flow, float *__restrict__ flow2,
+                                                        int ldf2) {
+    constexpr int V = CIN / 64;   // channels per lane (4 or 2)
+    static_assert(V == 4 || V == 2, "flowhead2: CIN must be 256 or 128");
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t M = (int64_t)B * H * W;
+    // per-lane weights: 9 taps x V channels x 2 outputs
+    float w0[9][V], w1[9][V];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            w0[t][v] = wk[((int64_t)t * CIN + lane * V + v) * 2];
+            w1[t][v] = wk[((int64_t)t * CIN + lane * V + v) * 2 + 1];
+        }
+    const float b0 = bias[0], b1 = bias[1];
+    constexpr int PPW = 8;   // pixels per wave
+    const int64_t mbase = ((int64_t)blockIdx.x * 4 + wid) * PPW;
+    for (int i = 0; i < PPW; ++i) {
+        const int64_t m = mbase + i;
+        if (m >= M) break;
+        const int px = (int)(m % W), py = (int)((m / W) % H);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;   // wave-uniform
+            const float *src = x + (m + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * ldx + lane * V;
+            float xv[V];
+            if (V == 4) {
+                const f32x4 q = *(const f32x4 *)src;
+                xv[0] = q[0]; xv[1] = q[1]; xv[2] = q[2]; xv[3] = q[3];
+            } else {
+                const float2 q = *(const float2 *)src;
+                xv[0] = q.x; xv[1] = q.y;
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                s0 = fmaf(xv[v], w0[t][v], s0);
+                s1 = fmaf(xv[v], w1[t][v], s1);
+            }
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) {
+            const float dx = s0 + b0, dy = s1 + b1;
+            float2 c = ((float2 *)coords1)[m];
+            c.x += dx;
+            c.y += dy;
+            ((float2 *)coords1)[m] = c;
+            ((float2 *)delta)[m] = make_float2(dx, dy);
+            const float2 f = make_float2(c.x - (float)px, c.y - (float)py);   // coords0 = (x, y) grid
+            ((float2 *)flow)[m] = f;
+            if (flow2) *(float2 *)(flow2 + m * ldf2) = f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// state preparation  [model.py:84-89]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) prepare_state_kernel(const float *__restrict__ cnet, int B, int h, int w,
+                                                            int hdim, int cdim, float *__restrict__ net,
+                                                            float *__restrict__ x, int ldx, int flow_slot,
+                                                            float *__restrict__ corr, int ldc, int corr_used,
+                                                            float *__restrict__ coords1, float *__restrict__ flow) {
+    const int64_t M = (int64_t)B * h * w;
+    const int per = hdim + cdim;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * per) return;
+    const int64_t m = i / per;
+    const int c = (int)(i - m * per);
+    const float v = cnet[i];
+    if (c < hdim)
+        net[m * hdim + c] = tanhf(v);
+    else
+        x[m * ldx + (c - hdim)] = fmaxf(v, 0.f);
+    if (c == 0) {
+        const int px = (int)(m % w), py = (int)((m / w) % h);
+        ((float2 *)coords1)[m] = make_float2((float)px, (float)py);
+        ((float2 *)flow)[m] = make_float2(0.f, 0.f);
+    }
+    // GRU input tail [flow | zero pad]: the flow slot starts at 0 and is rewritten every iteration
+    if (c < ldx - flow_slot) x[m * ldx + flow_slot + c] = 0.f;
+    // zero pad channels of the lookup output (never written by the lookup, read by convc1)
+    if (c < ldc - corr_used) corr[m * ldc + corr_used + c] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BasicUpdateBlock
+// workspace (floats per pixel): cor1 256 | corflo 256 [cor2 192 | flo2 64] | flo1 128 | z 128 | rh 128 | fm 512
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int WS_COR1 = 0, WS_CORFLO = 256, WS_FLO1 = 512, WS_Z = 640, WS_RH = 768, WS_FM = 896, WS_PER_PIX = 1408;
+constexpr int HDIM = 128, XDIM = 256, CORR_LD = 352, CORR_USED = 324;
+}   // namespace
+
+extern "C" int64_t raft_update_workspace_floats(int B, int h, int w) {
+    if (B <= 0 || h <= 0 || w <= 0) return 0;
+    return (int64_t)B * h * w * WS_PER_PIX;
+}
+
+static int check_state(const raft_state *st) {
+    RAFT_REQUIRE_PTR(st);
+    RAFT_REQUIRE_PTR(st->net);
+    RAFT_REQUIRE_PTR(st->x);
+    RAFT_REQUIRE_PTR(st->corr);
+    RAFT_REQUIRE_PTR(st->coords1);
+    RAFT_REQUIRE_PTR(st->flow);
+    RAFT_REQUIRE_PTR(st->delta);
+    RAFT_REQUIRE_PTR(st->mask);
+    RAFT_REQUIRE_PTR(st->ws);
+    return RAFT_OK;
+}
+
+extern "C" int raft_prepare_state_f32(const float *cnet, int B, int h, int w, const raft_state *st, void *stream) {
+    RAFT_REQUIRE_PTR(cnet);
+    int rc = check_state(st);
+    if (rc) return rc;
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
+    const int64_t total = (int64_t)B * h * w * (HDIM + 128);
+    prepare_state_kernel<<<raft_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(
+        cnet, B, h, w, HDIM, 128, st->net, st->x, XDIM, XDIM - 2, st->corr, CORR_LD, CORR_USED, st->coords1, st->flow);
+    return raft_launch_status();
+}
+
+static ConvArgs conv_args(const raft_conv_weights &wt, const float *a0, int lda0, int c0, const float *a1, int lda1,
+                          int c1, int B, int h, int w, int nvalid, float *o0, int ldo0) {
+    ConvArgs a = {};
+    a.a0 = a0; a.lda0 = lda0; a.c0 = c0; a.a1 = a1; a.lda1 = lda1; a.c1 = c1;
+    a.wp = wt.wp; a.bias = wt.bias; a.npad = wt.npad; a.nvalid = nvalid;
+    a.B = B; a.H = h; a.W = w; a.scale = 1.0f; a.o0 = o0; a.ldo0 = ldo0;
+    return a;
+}
+
+#define RAFT_TRY(expr)              \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != RAFT_OK) return rc__; \
+    } while (0)
+
+// Optional per-stage HIP-event recorder (profiling entry point only; see raft_iterate_basic_timed_f32).
+struct StageTimer {
+    hipEvent_t *ev;
+    int n, cap;
+    void mark(hipStream_t s) {
+        if (n < cap) (void)hipEventRecord(ev[n++], s);
+    }
+};
+#define RAFT_MARK()                 \
+    do {                            \
+        if (tm) tm->mark(s);        \
+    } while (0)
+
+static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h, int w, const raft_state *st,
+                             void *stream, StageTimer *tm) {
+    RAFT_REQUIRE_PTR(wts);
+    RAFT_TRY(check_state(st));
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = (int64_t)B * h * w;
+    float *ws = st->ws;
+    float *cor1 = ws + M * WS_COR1, *corflo = ws + M * WS_CORFLO, *flo1 = ws + M * WS_FLO1;
+    float *zb = ws + M * WS_Z, *rh = ws + M * WS_RH, *fm = ws + M * WS_FM;
+
+    // ---- BasicMotionEncoder (update.py:97-106)
+    {   // cor = relu(convc1(corr))            1x1, 324(+28 zero pad) -> 256
+        ConvArgs a = conv_args(wts->convc1, st->corr, CORR_LD, CORR_LD, nullptr, 0, 0, B, h, w, 256, cor1, 256);
+        RAFT_TRY(raft_launch_conv(a, 1, 1, EPI_RELU, s));
+        RAFT_MARK();
+    }
+    {   // cor = relu(convc2(cor))             3x3, 256 -> 192   -> corflo[:, 0:192]
+        ConvArgs a = conv_args(wts->convc2, cor1, 256, 256, nullptr, 0, 0, B, h, w, 192, corflo, 256);
+        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+        RAFT_MARK();
+    }
+    {   // flo = relu(convf1(flow))            7x7, 2 -> 128
+        const int xt = (w + 31) / 32;
+        conv7x7_c2_kernel<128><<<B * h * xt, 256, 0, s>>>(st->flow, wts->convf1.wp, wts->convf1.bias, B, h, w, flo1, 128);
+        RAFT_TRY(raft_launch_status());
+        RAFT_MARK();
+    }
+    {   // flo = relu(convf2(flo))             3x3, 128 -> 64    -> corflo[:, 192:256]
+        ConvArgs a = conv_args(wts->convf2, flo1, 128, 128, nullptr, 0, 0, B, h, w, 64, corflo + 192, 256);
+        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+        RAFT_MARK();
+    }
+    {   // out = relu(conv(cat[cor, flo]))     3x3, 256 -> 126   -> x[:, 128:254]; x[:, 254:256] = flow (kept by flowhead2)
+        ConvArgs a = conv_args(wts->conv, corflo, 256, 256, nullptr, 0, 0, B, h, w, 126, st->x + 128, XDIM);
+        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+        RAFT_MARK();
+    }
+    // ---- SepConvGRU (update.py:51-67): hx = [h | x]; [r*h | x]
+    for (int pass = 0; pass < 2; ++pass) {
+        const raft_conv_weights &wzr = pass == 0 ? wts->gru_zr1 : wts->gru_zr2;
+        const raft_conv_weights &wq = pass == 0 ? wts->gru_q1 : wts->gru_q2;
+        const int kh = pass == 0 ? 1 : 5, kw = pass == 0 ? 5 : 1;
+        {
+            ConvArgs a = conv_args(wzr, st->net, HDIM, HDIM, st->x, XDIM, XDIM, B, h, w, 2 * HDIM, zb, HDIM);
+            a.hid = HDIM; a.o1 = rh; a.ldo1 = HDIM; a.e0 = st->net; a.lde0 = HDIM;
+            RAFT_TRY(raft_launch_conv(a, kh, kw, EPI_GRU_ZR, s));
+            RAFT_MARK();
+        }
+        {
+            ConvArgs a = conv_args(wq, rh, HDIM, HDIM, st->x, XDIM, XDIM, B, h, w, HDIM, st->net, HDIM);
+            a.e0 = st->net; a.lde0 = HDIM; a.e1 = zb; a.lde1 = HDIM;
+            RAFT_TRY(raft_launch_conv(a, kh, kw, EPI_GRU_Q, s));
+            RAFT_MARK();
+        }
+    }
+    {   // relu(flow_head.conv1(net)) | relu(mask.0(net))   3x3, 128 -> 256 + 256
+        ConvArgs a = conv_args(wts->fh1_mask0, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 512, fm, 512);
+        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+        RAFT_MARK();
+    }
+    {   // delta = flow_head.conv2(.), coords1 += delta, flow = coords1 - coords0
+        flowhead2_kernel<256><<<raft_ceil_div(M, 32), 256, 0, s>>>(fm, 512, wts->fh2.wp, wts->fh2.bias, B, h, w,
+                                                                   st->delta, st->coords1, st->flow, st->x + 254, XDIM);
+        RAFT_TRY(raft_launch_status());
+        RAFT_MARK();
+    }
+    {   // mask = 0.25 * mask.2(.)             1x1, 256 -> 576
+        ConvArgs a = conv_args(wts->mask2, fm + 256, 512, 256, nullptr, 0, 0, B, h, w, 576, st->mask, 576);
+        a.scale = 0.25f;
+        RAFT_TRY(raft_launch_conv(a, 1, 1, EPI_LINEAR, s));
+        RAFT_MARK();
+    }
+    return RAFT_OK;
+}
+
+extern "C" int raft_update_basic_f32(const raft_basic_update_weights *wts, int B, int h, int w,
+                                     const raft_state *st, void *stream) {
+    return update_basic_impl(wts, B, h, w, st, stream, nullptr);
+}
+
+extern "C" int raft_iterate_basic_f32(const raft_basic_update_weights *wts, const float *pyr,
+                                      const int64_t *level_offsets, int B, int h, int w, int iters,
+                                      const raft_state *st, float *flow_up, void *stream) {
+    RAFT_REQUIRE_PTR(wts);
+    RAFT_REQUIRE_PTR(pyr);
+    RAFT_REQUIRE_PTR(level_offsets);
+    RAFT_REQUIRE_PTR(flow_up);
+    RAFT_TRY(check_state(st));
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0 && iters > 0, RAFT_E_SHAPE);
+    const int64_t up = (int64_t)B * 64 * h * w * 2;
+    for (int i = 0; i < iters; ++i) {
+        RAFT_TRY(raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream));
+        RAFT_TRY(update_basic_impl(wts, B, h, w, st, stream, nullptr));
+        RAFT_TRY(raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream));
+    }
+    return RAFT_OK;
+}
+
+// Profiling twin of raft_iterate_basic_f32: identical launches, plus a HIP event after every kernel
+// on `stream`; synchronises and accumulates per-stage milliseconds into stage_ms[RAFT_BASIC_STAGES]
+// (host array).  Used by bench.py for the live roofline numbers -- never on the product path.
+extern "C" int raft_iterate_basic_timed_f32(const raft_basic_update_weights *wts, const float *pyr,
+                                            const int64_t *level_offsets, int B, int h, int w, int iters,
+                                            const raft_state *st, float *flow_up, void *stream,
+                                            float *stage_ms) {
+    RAFT_REQUIRE_PTR(wts);
+    RAFT_REQUIRE_PTR(pyr);
+    RAFT_REQUIRE_PTR(level_offsets);
+    RAFT_REQUIRE_PTR(flow_up);
+    RAFT_REQUIRE_PTR(stage_ms);
+    RAFT_TRY(check_state(st));
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0 && iters > 0 && iters <= 64, RAFT_E_SHAPE);
+    hipStream_t s = (hipStream_t)stream;
+    const int per_iter = RAFT_BASIC_STAGES;
+    const int nev = iters * per_iter + 1;
+    hipEvent_t *ev = (hipEvent_t *)malloc(sizeof(hipEvent_t) * nev);
+    if (!ev) return (int)hipErrorOutOfMemory;
+    for (int i = 0; i < nev; ++i) (void)hipEventCreate(&ev[i]);
+    StageTimer tm = {ev, 0, nev};
+    const int64_t up = (int64_t)B * 64 * h * w * 2;
+    int rc = RAFT_OK;
+    tm.mark(s);
+    for (int i = 0; i < iters && rc == RAFT_OK; ++i) {
+        rc = raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream);
+        tm.mark(s);
+        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, &tm);
+        if (rc == RAFT_OK) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream);
+        tm.mark(s);
+    }
+    if (rc == RAFT_OK) rc = (int)hipStreamSynchronize(s);
+    if (rc == RAFT_OK && tm.n == nev) {
+        for (int k = 0; k < per_iter; ++k) stage_ms[k] = 0.f;
+        for (int i = 0; i < iters; ++i)
+            for (int k = 0; k < per_iter; ++k) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, ev[i * per_iter + k], ev[i * per_iter + k + 1]);
+                stage_ms[k] += ms;
+            }
+    }
+    for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+    free(ev);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SmallUpdateBlock  (reference update.py:70-85, 17-35, 109-125; model.py:190-226)
+//   net (M,96); x (M,160) = [inp 64 | motion 80 | flow 2 | 14 zero pad]; corr (M,224) = 196 + 28 pad
+// workspace (floats per pixel): corflo 128 [cor 96 | flo2 32] | flo1 64 | z 96 | rh 96 | fh 128
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int SW_CORFLO = 0, SW_FLO1 = 128, SW_Z = 192, SW_RH = 288, SW_FH = 384, SW_PER_PIX = 512;
+constexpr int S_HDIM = 96, S_CDIM = 64, S_XLD = 160, S_FLOW_SLOT = 144, S_CORR_LD = 224, S_CORR_USED = 196;
+}   // namespace
+
+extern "C" int64_t raft_small_update_workspace_floats(int B, int h, int w) {
+    if (B <= 0 || h <= 0 || w <= 0) return 0;
+    return (int64_t)B * h * w * SW_PER_PIX;
+}
+
+static int check_state_small(const raft_state *st) {
+    RAFT_REQUIRE_PTR(st);
+    RAFT_REQUIRE_PTR(st->net);
+    RAFT_REQUIRE_PTR(st->x);
+    RAFT_REQUIRE_PTR(st->corr);
+    RAFT_REQUIRE_PTR(st->coords1);
+    RAFT_REQUIRE_PTR(st->flow);
+    RAFT_REQUIRE_PTR(st->delta);
+    RAFT_REQUIRE_PTR(st->ws);
+    return RAFT_OK;
+}
+
+extern "C" int raft_prepare_state_small_f32(const float *cnet, int B, int h, int w, const raft_state *st,
+                                            void *stream) {
+    RAFT_REQUIRE_PTR(cnet);
+    RAFT_TRY(check_state_small(st));
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
+    const int64_t total = (int64_t)B * h * w * (S_HDIM + S_CDIM);
+    prepare_state_kernel<<<raft_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(
+        cnet, B, h, w, S_HDIM, S_CDIM, st->net, st->x, S_XLD, S_FLOW_SLOT, st->corr, S_CORR_LD, S_CORR_USED,
+        st->coords1, st->flow);
+    return raft_launch_status();
+}
+
+extern "C" int raft_update_small_f32(const raft_small_update_weights *wts, int B, int h, int w,
+                                     const raft_state *st, void *stream) {
+    RAFT_REQUIRE_PTR(wts);
+    RAFT_TRY(check_state_small(st));
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = (int64_t)B * h * w;
+    float *ws = st->ws;
+    float *corflo = ws + M * SW_CORFLO, *flo1 = ws + M * SW_FLO1, *zb = ws + M * SW_Z, *rh = ws + M * SW_RH;
+    float *fh = ws + M * SW_FH;
+    {   // cor = relu(convc1(corr))      1x1, 196(+28) -> 96     -> corflo[:, 0:96]
+        ConvArgs a = conv_args(wts->convc1, st->corr, S_CORR_LD, S_CORR_LD, nullptr, 0, 0, B, h, w, 96, corflo, 128);
+        RAFT_TRY(raft_launch_conv(a, 1, 1, EPI_RELU, s));
+    }
+    {   // flo = relu(convf1(flow))      7x7, 2 -> 64
+        const int xt = (w + 31) / 32;
+        conv7x7_c2_kernel<64><<<B * h * xt, 256, 0, s>>>(st->flow, wts->convf1.wp, wts->convf1.bias, B, h, w, flo1, 64);
+        RAFT_TRY(raft_launch_status());
+    }
+    {   // flo = relu(convf2(flo))       3x3, 64 -> 32           -> corflo[:, 96:128]
+        ConvArgs a = conv_args(wts->convf2, flo1, 64, 64, nullptr, 0, 0, B, h, w, 32, corflo + 96, 128);
+        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+    }
+    {   // out = relu(conv(cat[cor, flo])) 3x3, 128 -> 80        -> x[:, 64:144]
+        ConvArgs a = conv_args(wts->conv, corflo, 128, 128, nullptr, 0, 0, B, h, w, 80, st->x + 64, S_XLD);
+        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+    }
+    {   // ConvGRU (update.py:26-35), 3x3: z | r
+        ConvArgs a = conv_args(wts->gru_zr, st->net, S_HDIM, S_HDIM, st->x, S_XLD, S_XLD, B, h, w, 2 * S_HDIM, zb,
+                               S_HDIM);
+        a.hid = S_HDIM; a.o1 = rh; a.ldo1 = S_HDIM; a.e0 = st->net; a.lde0 = S_HDIM;
+        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_GRU_ZR, s));
+    }
+    {
+        ConvArgs a = conv_args(wts->gru_q, rh, S_HDIM, S_HDIM, st->x, S_XLD, S_XLD, B, h, w, S_HDIM, st->net, S_HDIM);
+        a.e0 = st->net; a.lde0 = S_HDIM; a.e1 = zb; a.lde1 = S_HDIM;
+        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_GRU_Q, s));
+    }
+    {   // relu(flow_head.conv1(net))    3x3, 96 -> 128
+        ConvArgs a = conv_args(wts->fh1, st->net, S_HDIM, S_HDIM, nullptr, 0, 0, B, h, w, 128, fh, 128);
+        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+    }
+    {   // delta = flow_head.conv2(.), coords1 += delta, flow = coords1 - coords0
+        flowhead2_kernel<128><<<raft_ceil_div(M, 32), 256, 0, s>>>(fh, 128, wts->fh2.wp, wts->fh2.bias, B, h, w,
+                                                                   st->delta, st->coords1, st->flow,
+                                                                   st->x + S_FLOW_SLOT, S_XLD);
+        RAFT_TRY(raft_launch_status());
+    }
+    return RAFT_OK;
+}
+
+extern "C" int raft_iterate_small_f32(const raft_small_update_weights *wts, const float *pyr,
+                                      const int64_t *level_offsets, int B, int h, int w, int iters,
+                                      const raft_state *st, float *flow_up, void *stream) {
+    RAFT_REQUIRE_PTR(wts);
+    RAFT_REQUIRE_PTR(pyr);
+    RAFT_REQUIRE_PTR(level_offsets);
+    RAFT_REQUIRE_PTR(flow_up);
+    RAFT_TRY(check_state_small(st));
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0 && iters > 0, RAFT_E_SHAPE);
+    const int64_t up = (int64_t)B * 64 * h * w * 2;
+    for (int i = 0; i < iters; ++i) {
+        RAFT_TRY(raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 3, st->corr, S_CORR_LD, stream));
+        RAFT_TRY(raft_update_small_f32(wts, B, h, w, st, stream));
+        RAFT_TRY(raft_upflow8_f32(st->flow, B, h, w, flow_up + i * up, stream));
+    }
+    return RAFT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// misc
+// ------------------------------------------------------------------------------------------------
+extern "C" int raft_version(void) { return RAFT_HIP_VERSION; }
+
+extern "C" const char *raft_error_string(int rc) {
+    switch (rc) {
+        case RAFT_OK: return "ok";
+        case RAFT_E_NULL: return "raft: required pointer is NULL";
+        case RAFT_E_SHAPE: return "raft: invalid or inconsistent dimension";
+        case RAFT_E_UNSUPPORTED: return "raft: configuration not instantiated (radius / channels / kernel size)";
+        case RAFT_E_ALIGN: return "raft: pointer or leading dimension not 16-byte aligned";
+    }
+    if (rc > 0) return hipGetErrorString((hipError_t)rc);
+    return "raft: unknown error";
+}

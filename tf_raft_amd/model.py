@@ -1,0 +1,198 @@
+"""Device mirror of reference ``tf_raft/model.py`` -- ``RAFT`` / ``SmallRAFT`` forward prediction.
+
+Same constructor and call signature as the reference (model.py:11, 68, 174, 190):
+
+    model = RAFT(drop_rate=0, iters=12, iters_pred=24)
+    flow_predictions = model([image1, image2], training=False)   # list of (bs, H, W, 2)
+
+``image1/2`` are ``(bs, H, W, 3)`` float arrays in 0..255 (NumPy or torch, host or device);
+the result is a Python list of ``iters_pred`` (``iters`` when ``training=True``) fp32 device
+tensors, ``[-1]`` the finest, each answering ``.numpy()`` like a TF eager tensor.
+
+Execution: encoders on PyTorch-ROCm, then everything on hand-written HIP kernels behind the C ABI
+(``include/raft_hip.h``): correlation volume build, and the whole recurrent loop
+(lookup -> update block -> coords update -> upsampling) enqueued by ONE ``raft_iterate_*`` call on
+the current HIP stream with no host synchronisation.  There is no CPU fallback.
+
+Out of scope (training plumbing of the reference, model.py:111-170): ``compile``, ``train_step``,
+``test_step``, ``reset_metrics``.  ``predict_step`` is provided.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _dev
+from . import weights as weights_mod
+from ._ffi import check
+from .layers.corr import CorrBlock, coords_grid, upflow8
+from .layers.extractor import BasicEncoder, SmallEncoder
+from .layers.update import BasicUpdateBlock, SmallUpdateBlock, UpdateState
+
+
+class RAFT:
+    """reference model.py:10-109."""
+
+    variant = 'raft'
+
+    def __init__(self, drop_rate=0, iters=12, iters_pred=24, weights: Optional[Dict[str, np.ndarray]] = None,
+                 seed=0, alternate_corr=False, **kwargs):
+        if kwargs:
+            raise TypeError(f'unexpected keyword arguments {sorted(kwargs)}')
+        self.hidden_dim = 128
+        self.context_dim = 128
+        self.corr_levels = 4
+        self.corr_radius = 4
+        self.drop_rate = drop_rate
+        self.iters = iters
+        self.iters_pred = iters_pred
+        self.alternate_corr = alternate_corr
+        self._state = None
+        _dev.require_gpu()
+        _dev.lib()
+        if weights is None:
+            weights = weights_mod.init_weights(self.variant, seed)     # Keras default initialisers
+        weights_mod.check_weights(self.variant, weights)
+        self._build(weights)
+
+    def _build(self, weights):
+        self.fnet = BasicEncoder(output_dim=256, norm_type='instance', drop_rate=self.drop_rate,
+                                 weights=weights, prefix='fnet')
+        self.cnet = BasicEncoder(output_dim=self.hidden_dim + self.context_dim, norm_type='batch',
+                                 drop_rate=self.drop_rate, weights=weights, prefix='cnet')
+        self.update_block = BasicUpdateBlock(filters=self.hidden_dim, weights=weights, prefix='update_block')
+
+    # ---- weights ------------------------------------------------------------------------------
+    def set_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        weights_mod.check_weights(self.variant, weights)
+        self.fnet.set_weights(weights)
+        self.cnet.set_weights(weights)
+        self.update_block.set_weights(weights)
+
+    def load_weights(self, path: str) -> None:
+        """Load a ``.npz`` written by ``tf_raft_amd.weights.save_weights`` (Keras layout).  The
+        reference's TF checkpoint format (README.md:66-96) needs a tensor-bundle reader: not built."""
+        self.set_weights(weights_mod.load_weights(path))
+
+    # ---- reference helpers ----------------------------------------------------------------------
+    def initialize_flow(self, image):
+        """reference model.py:32-37."""
+        bs, h, w, _ = image.shape
+        return coords_grid(bs, h // 8, w // 8), coords_grid(bs, h // 8, w // 8)
+
+    def upsample_flow(self, flow, mask):
+        """reference model.py:39-66.  flow (bs, h, w, 2), mask (bs, h, w, 576) -> (bs, 8h, 8w, 2)."""
+        flow = _dev.to_device(flow)
+        mask = _dev.to_device(mask)
+        bs, h, w, _ = flow.shape
+        if tuple(mask.shape) != (bs, h, w, 576) or flow.shape[-1] != 2:
+            raise ValueError(f'expected flow (bs,h,w,2) and mask (bs,h,w,576), got {tuple(flow.shape)}, {tuple(mask.shape)}')
+        out = torch.empty((bs, 8 * h, 8 * w, 2), device=flow.device, dtype=torch.float32)
+        check(_dev.lib().raft_upsample_convex_f32(_dev.ptr(flow), _dev.ptr(mask), bs, h, w, _dev.ptr(out),
+                                                  _dev.stream_ptr()), 'upsample_convex')
+        return _dev.wrap(out)
+
+    # ---- forward ----------------------------------------------------------------------------------
+    def _get_state(self, B, h, w, device) -> UpdateState:
+        st = self._state
+        if st is None or (st.B, st.h, st.w) != (B, h, w) or st.net.device != device:
+            st = UpdateState(self.variant, B, h, w, device)
+            self._state = st
+        return st
+
+    def _prepare(self, cnet, st):
+        check(_dev.lib().raft_prepare_state_f32(_dev.ptr(cnet), st.B, st.h, st.w, C.byref(st.c),
+                                                _dev.stream_ptr()), 'prepare_state')
+
+    def _iterate(self, corr: CorrBlock, st, iters, flow_up):
+        check(_dev.lib().raft_iterate_basic_f32(C.byref(self.update_block.c), _dev.ptr(corr._pyr), corr._off,
+                                                st.B, st.h, st.w, iters, C.byref(st.c), _dev.ptr(flow_up),
+                                                _dev.stream_ptr()), 'iterate_basic')
+
+    def _iterate_alternate(self, corr: CorrBlock, st, iters, flow_up):
+        g = st.g
+        for i in range(iters):
+            corr.retrieve(st.coords1, out=st.corr, ld_out=g['corr_ld'])
+            self.update_block.step(st)
+            self._upsample_into(st, flow_up[i])
+
+    def _upsample_into(self, st, out):
+        check(_dev.lib().raft_upsample_convex_f32(_dev.ptr(st.flow), _dev.ptr(st.mask), st.B, st.h, st.w,
+                                                  _dev.ptr(out), _dev.stream_ptr()), 'upsample_convex')
+
+    def __call__(self, inputs, training=False):
+        return self.call(inputs, training)
+
+    def call(self, inputs, training=False):
+        """reference model.py:68-109."""
+        image1, image2 = inputs
+        image1 = _dev.to_device(image1)
+        image2 = _dev.to_device(image2)
+        if image1.dim() != 4 or image1.shape[-1] != 3 or image1.shape != image2.shape:
+            raise ValueError(f'images must both be (bs, H, W, 3), got {tuple(image1.shape)} / {tuple(image2.shape)}')
+        B, H, W, _ = image1.shape
+        if H % 8 or W % 8:
+            raise ValueError(f'H and W must be multiples of 8 (got {H}x{W})')   # model.py:35 uses h//8
+        image1 = 2 * (image1 / 255.0) - 1.0                                     # model.py:70-71
+        image2 = 2 * (image2 / 255.0) - 1.0
+
+        fmap1, fmap2 = self.fnet([image1, image2], training=training)          # model.py:74
+        correlation = CorrBlock(fmap1, fmap2, num_levels=self.corr_levels, radius=self.corr_radius,
+                                alternate=self.alternate_corr)                  # model.py:77
+        cnet = self.cnet(image1, training=training)                            # model.py:82
+
+        h, w = H // 8, W // 8
+        st = self._get_state(B, h, w, image1.device)
+        self._prepare(cnet, st)                                                 # model.py:84-89
+        iters = self.iters if training else self.iters_pred
+        flow_up = torch.empty((iters, B, H, W, 2), device=image1.device, dtype=torch.float32)
+        if self.alternate_corr:
+            self._iterate_alternate(correlation, st, iters, flow_up)
+        else:
+            self._iterate(correlation, st, iters, flow_up)                      # model.py:93-106
+        self._last_correlation = correlation                                    # keep buffers alive until the stream drains
+        return [_dev.wrap(flow_up[i]) for i in range(iters)]                    # model.py:109
+
+    def predict_step(self, data):
+        """reference model.py:160-166."""
+        image1, image2, *_ = data
+        return self([image1, image2], training=False)[-1]
+
+
+class SmallRAFT(RAFT):
+    """reference model.py:173-226."""
+
+    variant = 'small'
+
+    def __init__(self, drop_rate=0, iters=12, iters_pred=24, **kwargs):
+        super().__init__(drop_rate, iters, iters_pred, **kwargs)
+        self.hidden_dim = 96
+        self.context_dim = 64
+        self.corr_levels = 4
+        self.corr_radius = 3
+
+    def _build(self, weights):
+        self.fnet = SmallEncoder(output_dim=128, norm_type='instance', drop_rate=self.drop_rate,
+                                 weights=weights, prefix='fnet')
+        self.cnet = SmallEncoder(output_dim=96 + 64, norm_type=None, drop_rate=self.drop_rate,
+                                 weights=weights, prefix='cnet')
+        self.update_block = SmallUpdateBlock(filters=96, weights=weights, prefix='update_block')
+
+    def _prepare(self, cnet, st):
+        check(_dev.lib().raft_prepare_state_small_f32(_dev.ptr(cnet), st.B, st.h, st.w, C.byref(st.c),
+                                                      _dev.stream_ptr()), 'prepare_state_small')
+
+    def _iterate(self, corr, st, iters, flow_up):
+        check(_dev.lib().raft_iterate_small_f32(C.byref(self.update_block.c), _dev.ptr(corr._pyr), corr._off,
+                                                st.B, st.h, st.w, iters, C.byref(st.c), _dev.ptr(flow_up),
+                                                _dev.stream_ptr()), 'iterate_small')
+
+    def _upsample_into(self, st, out):
+        check(_dev.lib().raft_upflow8_f32(_dev.ptr(st.flow), st.B, st.h, st.w, _dev.ptr(out),
+                                          _dev.stream_ptr()), 'upflow8')
+
+    def upsample_flow(self, flow, mask=None):
+        return upflow8(flow)

@@ -1,0 +1,113 @@
+"""Host-side repacking of Keras-layout weights into the layouts the HIP kernels consume.
+
+Packed conv layout (include/raft_hip.h): for a Keras kernel ``(kh, kw, Cin, Cout)`` whose input
+is the concatenation of channel groups ``sources = [(c_real, c_pad), ...]``::
+
+    wp[t, k // 4, n, k % 4] = kernel[t // kw, t % kw, k_real, n]
+
+``k`` runs over the padded channel axis (each source padded with zero rows to ``c_pad``, a
+multiple of 32) and ``n`` over ``npad`` (Cout rounded up to a multiple of 64, zero columns).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pack_conv(kernel: np.ndarray, bias: np.ndarray,
+              sources: Sequence[Tuple[int, int]] = None) -> Tuple[np.ndarray, np.ndarray, int]:
+    """Return (wp float32[T, Kpad/4, npad, 4], bias float32[npad], npad)."""
+    kernel = np.asarray(kernel, dtype=np.float32)
+    kh, kw, cin, cout = kernel.shape
+    if sources is None:
+        sources = [(cin, round_up(cin, 32))]
+    if sum(c for c, _ in sources) != cin:
+        raise ValueError(f'sources {sources} do not add up to Cin={cin}')
+    for _, cp in sources:
+        if cp % 32:
+            raise ValueError('padded source channel counts must be multiples of 32')
+    kpad = sum(cp for _, cp in sources)
+    npad = round_up(cout, 64)
+    full = np.zeros((kh * kw, kpad, npad), dtype=np.float32)
+    k_src = 0
+    k_dst = 0
+    flat = kernel.reshape(kh * kw, cin, cout)
+    for c, cp in sources:
+        full[:, k_dst:k_dst + c, :cout] = flat[:, k_src:k_src + c, :]
+        k_src += c
+        k_dst += cp
+    wp = full.reshape(kh * kw, kpad // 4, 4, npad).transpose(0, 1, 3, 2)
+    b = np.zeros((npad,), dtype=np.float32)
+    b[:cout] = np.asarray(bias, dtype=np.float32)
+    return np.ascontiguousarray(wp), b, npad
+
+
+def fuse_n(weights: Dict[str, np.ndarray], names: Sequence[str]):
+    """Concatenate several convolutions over the same input along the output-channel axis."""
+    k = np.concatenate([weights[f'{n}/kernel'] for n in names], axis=3)
+    b = np.concatenate([weights[f'{n}/bias'] for n in names], axis=0)
+    return k, b
+
+
+def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_block') -> List[Tuple[str, np.ndarray, np.ndarray, int]]:
+    """[(field, packed_kernel, bias, npad)] for ``raft_basic_update_weights``
+    (reference update.py:128-153; GRU input order hx = [h | inp | motion(126) | flow(2)])."""
+    p = prefix
+    w = weights
+    out = []
+
+    def conv(field, name, sources=None):
+        wp, b, npad = pack_conv(w[f'{name}/kernel'], w[f'{name}/bias'], sources)
+        out.append((field, wp, b, npad))
+
+    conv('convc1', f'{p}/encoder/convc1', [(324, 352)])
+    conv('convc2', f'{p}/encoder/convc2')
+    out.append(('convf1', np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel'], dtype=np.float32).reshape(98, 128),
+                np.asarray(w[f'{p}/encoder/convf1/bias'], dtype=np.float32), 128))
+    conv('convf2', f'{p}/encoder/convf2')
+    conv('conv', f'{p}/encoder/conv')
+    for s in ('1', '2'):
+        k, b = fuse_n(w, [f'{p}/gru/convz{s}', f'{p}/gru/convr{s}'])
+        wp, bb, npad = pack_conv(k, b, [(128, 128), (256, 256)])
+        out.append((f'gru_zr{s}', wp, bb, npad))
+        wp, bb, npad = pack_conv(w[f'{p}/gru/convq{s}/kernel'], w[f'{p}/gru/convq{s}/bias'], [(128, 128), (256, 256)])
+        out.append((f'gru_q{s}', wp, bb, npad))
+    k, b = fuse_n(w, [f'{p}/flow_head/conv1', f'{p}/mask/0'])
+    wp, bb, npad = pack_conv(k, b)
+    out.append(('fh1_mask0', wp, bb, npad))
+    out.append(('fh2', np.ascontiguousarray(w[f'{p}/flow_head/conv2/kernel'], dtype=np.float32).reshape(9, 256, 2),
+                np.asarray(w[f'{p}/flow_head/conv2/bias'], dtype=np.float32), 2))
+    conv('mask2', f'{p}/mask/2')
+    return out
+
+
+def pack_small_update(weights: Dict[str, np.ndarray], prefix: str = 'update_block'):
+    """[(field, packed_kernel, bias, npad)] for ``raft_small_update_weights``
+    (reference update.py:109-125; hx = [h(96) | inp(64) | motion(80) | flow(2)], x padded to 160)."""
+    p = prefix
+    w = weights
+    out = []
+
+    def conv(field, name, sources=None):
+        wp, b, npad = pack_conv(w[f'{name}/kernel'], w[f'{name}/bias'], sources)
+        out.append((field, wp, b, npad))
+
+    conv('convc1', f'{p}/encoder/convc1', [(196, 224)])
+    out.append(('convf1', np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel'], dtype=np.float32).reshape(98, 64),
+                np.asarray(w[f'{p}/encoder/convf1/bias'], dtype=np.float32), 64))
+    conv('convf2', f'{p}/encoder/convf2')
+    conv('conv', f'{p}/encoder/conv')
+    k, b = fuse_n(w, [f'{p}/gru/convz', f'{p}/gru/convr'])
+    wp, bb, npad = pack_conv(k, b, [(96, 96), (146, 160)])
+    out.append(('gru_zr', wp, bb, npad))
+    wp, bb, npad = pack_conv(w[f'{p}/gru/convq/kernel'], w[f'{p}/gru/convq/bias'], [(96, 96), (146, 160)])
+    out.append(('gru_q', wp, bb, npad))
+    conv('fh1', f'{p}/flow_head/conv1')
+    out.append(('fh2', np.ascontiguousarray(w[f'{p}/flow_head/conv2/kernel'], dtype=np.float32).reshape(9, 128, 2),
+                np.asarray(w[f'{p}/flow_head/conv2/bias'], dtype=np.float32), 2))
+    return out

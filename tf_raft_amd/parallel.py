@@ -1,0 +1,86 @@
+"""Data-parallel prediction: one process per GPU, image-pair batches sharded across ranks,
+predictions all-gathered over RCCL/xGMI (``torch.distributed`` backend ``"nccl"`` IS RCCL on ROCm;
+``"gloo"`` is used by the CPU tests).
+
+The reference has no distributed code at all; image pairs are independent end to
+end (per-sample instance norm, frozen batch-norm statistics, per-sample correlation volume), so the
+only communication is ONE all-gather of the final predictions -- there is no data-path collective
+inside the forward pass.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of ``total`` items for ``rank``; the first ``total % world_size``
+    ranks get one extra item (ragged totals are allowed, empty shards too)."""
+    if world_size <= 0 or not 0 <= rank < world_size or total < 0:
+        raise ValueError(f'bad shard request total={total} rank={rank} world_size={world_size}')
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_batch(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """All-gather per-rank shards (dim 0) of a batch of ``total`` items, in rank order.
+    Ragged shards are padded to the largest shard for the collective and trimmed afterwards."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    sizes = [hi - lo for lo, hi in sizes]
+    mx = max(sizes)
+    if local.shape[0] != sizes[dist.get_rank(group)]:
+        raise ValueError(f'local shard has {local.shape[0]} items, expected {sizes[dist.get_rank(group)]}')
+    if local.shape[0] < mx:
+        pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    local = local.contiguous()
+    if len(set(sizes)) == 1:
+        out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+
+
+def predict_sharded(predict: Callable[[Sequence], List[torch.Tensor]], image1, image2, group=None,
+                    gather_all_iterations: bool = False):
+    """Run ``predict([image1_shard, image2_shard])`` on this rank's contiguous shard of the global
+    batch and all-gather the result.
+
+    ``image1/2`` are the GLOBAL ``(B, H, W, 3)`` batches (every rank passes the same arrays).
+    Returns the gathered ``flow_predictions[-1]`` of shape ``(B, H, W, 2)``, or the list of all
+    iterations when ``gather_all_iterations`` is set.
+    """
+    total = image1.shape[0]
+    if dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_range(total, rank, world)
+    if hi > lo:
+        preds = predict([image1[lo:hi], image2[lo:hi]])
+    else:
+        preds = None
+    if world == 1:
+        return preds if gather_all_iterations else preds[-1]
+    # ranks with an empty shard still have to join the collective with a correctly shaped buffer
+    meta = [None]
+    if preds is not None:
+        meta[0] = (len(preds), tuple(preds[-1].shape[1:]), preds[-1].dtype, str(preds[-1].device))
+    metas: List[Optional[tuple]] = [None] * world
+    dist.all_gather_object(metas, meta[0], group=group)
+    n_iter, tail, dtype, _ = next(m for m in metas if m is not None)
+    if preds is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' \
+            else torch.device('cpu')
+        preds = [torch.zeros((0,) + tail, dtype=dtype, device=device) for _ in range(n_iter)]
+    if gather_all_iterations:
+        return [all_gather_batch(torch.as_tensor(p), total, group) for p in preds]
+    return all_gather_batch(torch.as_tensor(preds[-1]), total, group)
