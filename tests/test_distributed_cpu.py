@@ -1,0 +1,92 @@
+"""The N > 1 path (tf_raft_amd/parallel.py) on CPU: two processes, gloo backend, 127.0.0.1.
+The per-shard 'model' is the CPU oracle on tiny inputs (tests may use the oracle); what is under
+test is the sharding + all-gather logic that bench.py and multi-GPU users run over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from tf_raft_amd.parallel import all_gather_batch, predict_sharded, shard_range
+
+
+def test_shard_range_partitions_every_total():
+    for total in range(0, 20):
+        for world in range(1, 9):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(64, 3, 8) == (24, 32)                       # BASELINE config 3: 8 pairs per GPU
+    with pytest.raises(ValueError):
+        shard_range(4, 4, 4)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import oracle
+        from tf_raft_amd import weights as wm
+        rng = np.random.default_rng(0)
+        i1 = rng.uniform(0, 255, (total, 32, 32, 3)).astype(np.float32)
+        i2 = rng.uniform(0, 255, (total, 32, 32, 3)).astype(np.float32)
+        model = oracle.SmallRAFT(wm.init_weights('small', 0), iters_pred=2)
+
+        def predict(inputs):
+            return [torch.as_tensor(p) for p in model(inputs)]
+
+        last = predict_sharded(predict, i1, i2)
+        every = predict_sharded(predict, i1, i2, gather_all_iterations=True)
+        # ragged all-gather on its own
+        lo, hi = shard_range(total, rank, world)
+        local = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1)
+        g = all_gather_batch(local, total)
+        if rank == 0:
+            np.save(os.path.join(tmp, 'last.npy'), last.numpy())
+            np.save(os.path.join(tmp, 'every1.npy'), every[1].numpy())
+            np.save(os.path.join(tmp, 'g.npy'), g.numpy())
+            np.save(os.path.join(tmp, 'n_every.npy'), np.array(len(every)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('total', [4, 3, 1])
+def test_two_rank_sharded_prediction_equals_single_process(tmp_path, total):
+    """total=3 is a ragged split (2 + 1); total=1 leaves rank 1 with an empty shard."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    import oracle
+    from tf_raft_amd import weights as wm
+    rng = np.random.default_rng(0)
+    i1 = rng.uniform(0, 255, (total, 32, 32, 3)).astype(np.float32)
+    i2 = rng.uniform(0, 255, (total, 32, 32, 3)).astype(np.float32)
+    want = oracle.SmallRAFT(wm.init_weights('small', 0), iters_pred=2)([i1, i2])
+    last = np.load(tmp_path / 'last.npy')
+    assert last.shape == (total, 32, 32, 2)
+    np.testing.assert_allclose(last, want[-1], atol=1e-4)
+    np.testing.assert_allclose(np.load(tmp_path / 'every1.npy'), want[1], atol=1e-4)
+    assert int(np.load(tmp_path / 'n_every.npy')) == 2
+    np.testing.assert_array_equal(np.load(tmp_path / 'g.npy')[:, 0], np.arange(total))
+
+
+def test_single_process_passthrough():
+    t = torch.arange(6.0).reshape(3, 2)
+    assert all_gather_batch(t, 3) is t
+    out = predict_sharded(lambda inp: [inp[0] * 2, inp[0] * 3], t, t)
+    np.testing.assert_array_equal(out.numpy(), (t * 3).numpy())

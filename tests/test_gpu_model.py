@@ -61,7 +61,30 @@ def test_output_is_list_of_iters_flows(cls_name):
         assert tuple(flow.shape) == (4, 64, 96, 2)
         assert np.isfinite(flow.numpy()).all()
     last = model.predict_step((image1, image2))
-    np.testing.assert_array_equal(last.numpy(), out[-1].numpy())
+    # not bit-equal across calls: MIOpen may pick a different convolution solver for the encoders
+    # on a repeated shape; the HIP loop itself is deterministic (test_hip_loop_is_deterministic)
+    np.testing.assert_allclose(last.numpy(), out[-1].numpy(), atol=1e-3)
+
+
+def test_hip_loop_is_deterministic():
+    """Same feature maps, same state -> bit-identical predictions from two runs of the HIP loop."""
+    import tf_raft_amd
+    from tf_raft_amd.layers.corr import CorrBlock
+    model = tf_raft_amd.RAFT(iters_pred=6)
+    i1, i2 = _images(5, 2, 128, 192)
+    x1 = torch.as_tensor(2 * (i1 / 255.0) - 1.0)
+    x2 = torch.as_tensor(2 * (i2 / 255.0) - 1.0)
+    fmap1, fmap2 = model.fnet([x1, x2])
+    cnet = model.cnet(x1)
+    runs = []
+    for _ in range(2):
+        corr = CorrBlock(fmap1, fmap2, 4, 4)
+        st = model._get_state(2, 16, 24, fmap1.device)
+        model._prepare(cnet, st)
+        flow_up = torch.empty((6, 2, 128, 192, 2), device=fmap1.device)
+        model._iterate(corr, st, 6, flow_up)
+        runs.append(_np(flow_up))
+    np.testing.assert_array_equal(runs[0], runs[1])
 
 
 def test_shim_import_path_and_bad_inputs():

@@ -1,0 +1,193 @@
+"""Host-side logic that needs no GPU: weight tables, packing, the C-ABI library (loads, exports
+every symbol declared in include/raft_hip.h, validates arguments before touching a device),
+loud failure without a GPU.  CPU only -- no compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from tf_raft_amd import _ffi, packing
+from tf_raft_amd import weights as wm
+
+
+# ---------------------------------------------------------------- weights
+def test_parameter_counts_match_the_reference_architecture():
+    """SURVEY 8a parameter inventory (Keras layer shapes of reference model.py / update.py / extractor.py)."""
+    w = wm.init_weights('raft', 0)
+    assert wm.count_params(w) == 5263296
+    assert wm.count_params(w, 'fnet') == 1069728
+    assert wm.count_params(w, 'cnet') == 1072608
+    assert wm.count_params(w, 'update_block') == 3120960
+    s = wm.init_weights('small', 0)
+    assert wm.count_params(s) == 1874130
+    assert wm.count_params(s, 'update_block') == 876530
+
+
+def test_default_weights_are_keras_defaults_and_seeded():
+    a, b = wm.init_weights('raft', 7), wm.init_weights('raft', 7)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    k = a['update_block/gru/convz1/kernel']
+    assert k.shape == (1, 5, 384, 128)
+    limit = np.sqrt(6.0 / (5 * 384 + 5 * 128))
+    assert np.abs(k).max() <= limit and np.abs(k).max() > 0.9 * limit
+    assert not a['update_block/gru/convz1/bias'].any()
+    assert np.all(a['cnet/norm1/moving_variance'] == 1) and np.all(a['fnet/norm1/gamma'] == 1)
+    p = wm.init_weights('raft', 7, perturb=True)
+    assert p['update_block/gru/convz1/bias'].any()
+    wm.check_weights('raft', a)
+    with pytest.raises(ValueError):
+        wm.check_weights('small', a)
+    bad = dict(a)
+    bad['fnet/conv1/kernel'] = np.zeros((3, 3, 3, 64), np.float32)
+    with pytest.raises(ValueError):
+        wm.check_weights('raft', bad)
+
+
+def test_save_load_roundtrip(tmp_path):
+    w = wm.init_weights('small', 1, perturb=True)
+    path = str(tmp_path / 'w.npz')
+    wm.save_weights(path, w)
+    r = wm.load_weights(path)
+    assert list(r) == list(w) and all(np.array_equal(r[k], w[k]) for k in w)
+
+
+def test_invalid_norm_type_raises_like_the_reference():
+    with pytest.raises(ValueError, match='Invalid norm_type'):
+        wm.encoder_entries('fnet', 'basic', 'layer', 128)         # reference extractor.py:16
+
+
+# ---------------------------------------------------------------- packing
+def _unpacked_conv(x, wp, bias, kh, kw, srcs_pad, nvalid):
+    """Evaluate the packed layout exactly the way the kernel indexes it (NumPy, tiny sizes)."""
+    B, H, W, kpad = x.shape
+    T, kq, npad, four = wp.shape
+    assert four == 4 and kq * 4 == kpad and T == kh * kw
+    out = np.zeros((B, H, W, nvalid), np.float64)
+    for t in range(T):
+        dy, dx = t // kw - (kh - 1) // 2, t % kw - (kw - 1) // 2
+        for k in range(kpad):
+            wrow = wp[t, k // 4, :nvalid, k % 4]
+            shifted = np.zeros((B, H, W))
+            ys = slice(max(0, -dy), min(H, H - dy))
+            xs = slice(max(0, -dx), min(W, W - dx))
+            shifted[:, ys, xs] = x[:, ys.start + dy:ys.stop + dy, xs.start + dx:xs.stop + dx, k]
+            out += shifted[..., None] * wrow
+    return out + bias[:nvalid]
+
+
+@pytest.mark.parametrize('ksize', [(1, 1), (3, 3), (1, 5), (5, 1)])
+def test_pack_conv_layout_reproduces_the_convolution(rng, ksize):
+    from oracle import tf_ops
+    kh, kw = ksize
+    c_a, c_b, cout = 5, 7, 6
+    kernel = rng.normal(size=(kh, kw, c_a + c_b, cout)).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    wp, b, npad = packing.pack_conv(kernel, bias, [(c_a, 32), (c_b, 32)])
+    assert wp.shape == (kh * kw, 16, 64, 4) and npad == 64 and b.shape == (64,)
+    xa = rng.normal(size=(1, 5, 6, c_a)).astype(np.float32)
+    xb = rng.normal(size=(1, 5, 6, c_b)).astype(np.float32)
+    xpad = np.zeros((1, 5, 6, 64), np.float32)
+    xpad[..., :c_a] = xa
+    xpad[..., 32:32 + c_b] = xb
+    got = _unpacked_conv(xpad, wp, b, kh, kw, None, cout)
+    want = tf_ops.conv2d(torch.as_tensor(np.concatenate([xa, xb], -1)).double(),
+                         torch.as_tensor(kernel).double(), torch.as_tensor(bias).double()).numpy()
+    np.testing.assert_allclose(got, want, atol=1e-5)
+    assert not wp[:, :, cout:, :].any()                              # zero N padding
+
+
+def test_pack_conv_rejects_bad_sources():
+    k = np.zeros((1, 1, 8, 4), np.float32)
+    with pytest.raises(ValueError):
+        packing.pack_conv(k, np.zeros(4), [(5, 32)])
+    with pytest.raises(ValueError):
+        packing.pack_conv(k, np.zeros(4), [(8, 20)])
+
+
+def test_pack_update_blocks_cover_every_struct_field():
+    basic = packing.pack_basic_update({k: v for k, v in wm.init_weights('raft', 0).items()})
+    assert [f for f, *_ in basic] == [n for n, _ in _ffi.BasicUpdateWeights._fields_]
+    zr = dict((f, (wp, b, n)) for f, wp, b, n in basic)['gru_zr1']
+    assert zr[0].shape == (5, 96, 256, 4) and zr[2] == 256           # [z | r] fused along N
+    small = packing.pack_small_update(wm.init_weights('small', 0))
+    assert [f for f, *_ in small] == [n for n, _ in _ffi.SmallUpdateWeights._fields_]
+    szr = dict((f, (wp, b, n)) for f, wp, b, n in small)['gru_zr']
+    assert szr[0].shape == (9, 64, 192, 4)                           # K = 96 + 160 (146 padded)
+
+
+# ---------------------------------------------------------------- C ABI
+def _declared_functions():
+    with open(os.path.join(ROOT, 'include', 'raft_hip.h')) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(raft_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    names = _declared_functions()
+    assert len(names) >= 20
+    lib = C.CDLL(_ffi.library_path()) if os.path.exists(_ffi.library_path()) else None
+    if lib is None:
+        lib = C.CDLL(__import__('tf_raft_amd.build', fromlist=['x']).build_library(verbose=False))
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/raft_hip.h but not exported'
+    assert sorted(_ffi.EXPORTED_SYMBOLS) == names, 'ctypes signature table and header disagree'
+    typed = _ffi.load_library()
+    assert typed.raft_version() == 100
+    assert b'NULL' in typed.raft_error_string(-1)
+    assert typed.raft_error_string(0) == b'ok'
+
+
+def test_pyramid_layout_host_helper():
+    lib = _ffi.load_library()
+    off = (C.c_int64 * 5)()
+    lh, lw = (C.c_int * 4)(), (C.c_int * 4)()
+    assert lib.raft_corr_pyramid_layout(1, 56, 64, 4, off, lh, lw) == 0
+    assert list(lh) == [56, 28, 14, 7] and list(lw) == [64, 32, 16, 8]        # reference corr.py:112-114
+    n = 56 * 64
+    assert list(off) == [0, n * n, n * n + n * 896, n * n + n * (896 + 224), n * (n + 896 + 224 + 56)]
+    assert lib.raft_corr_pyramid_layout(4, 8, 12, 4, off, lh, lw) == 0         # reference test size 64x96
+    assert list(lh) == [8, 4, 2, 1] and list(lw) == [12, 6, 3, 1]
+    assert lib.raft_corr_pyramid_layout(1, 4, 4, 4, off, lh, lw) == -2         # pooled away: RAFT_E_SHAPE
+    assert lib.raft_corr_pyramid_layout(1, 8, 8, 5, off, lh, lw) == -3         # RAFT_E_UNSUPPORTED
+    assert lib.raft_corr_build_workspace_floats(2, 56, 64, 256, 4) == 2 * 4760 * 256
+    assert lib.raft_update_workspace_floats(4, 56, 64) == 4 * 3584 * 1408
+
+
+def test_argument_errors_are_returned_before_any_device_work():
+    lib = _ffi.load_library()
+    off = (C.c_int64 * 5)(0, 1, 2, 3, 4)
+    assert lib.raft_corr_lookup_f32(None, off, None, 1, 8, 8, 4, 4, None, 324, None) == -1
+    assert lib.raft_coords_grid_f32(None, 1, 8, 8, None) == -1
+    assert lib.raft_upsample_convex_f32(None, None, 1, 8, 8, None, None) == -1
+    assert lib.raft_corr_build_f32(None, None, 1, 8, 8, 256, 4, None, off, None, None) == -1
+    assert lib.raft_update_basic_f32(None, 1, 8, 8, None, None) == -1
+    with pytest.raises(ValueError, match='NULL'):
+        _ffi.check(-1, 'x')
+    with pytest.raises(ValueError):
+        _ffi.check(-2)
+
+
+def test_product_path_fails_loudly_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import tf_raft_amd
+    from tf_raft_amd.layers.corr import coords_grid
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        tf_raft_amd.RAFT()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        coords_grid(1, 4, 4)
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure; nothing under tf_raft_amd/ or tf_raft/ may reference it."""
+    for pkg in ('tf_raft_amd', 'tf_raft'):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for fn in files:
+                if fn.endswith('.py'):
+                    with open(os.path.join(dirpath, fn)) as f:
+                        src = f.read()
+                    assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(dirpath, fn)

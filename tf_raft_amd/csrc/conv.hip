@@ -67,6 +67,11 @@ int raft_launch_conv(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s) 
     if (a.c0 <= 0 || a.c0 % 32 || a.c1 < 0 || a.c1 % 32 || a.npad <= 0 || a.npad % 64) return RAFT_E_UNSUPPORTED;
     if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
     if (!raft_aligned16(a.a0) || !raft_aligned16(a.wp) || (a.c1 && !raft_aligned16(a.a1))) return RAFT_E_ALIGN;
+    {   // the A tiles are fetched through 32-bit buffer offsets: each source must span < 2 GiB
+        const int64_t M = (int64_t)a.B * a.H * a.W;
+        const int64_t e0 = ((M - 1) * a.lda0 + a.c0) * 4, e1 = a.c1 ? ((M - 1) * a.lda1 + a.c1) * 4 : 0;
+        if (e0 >= (int64_t)1 << 31 || e1 >= (int64_t)1 << 31) return RAFT_E_UNSUPPORTED;
+    }
     int bm = 64, bn = 64;
     pick_tile((int64_t)a.B * a.H * a.W, a.npad, &bm, &bn);
     if (kh == 1 && kw == 1) return launch_conv_epi<1, 1>(a, epi, bm, bn, s);

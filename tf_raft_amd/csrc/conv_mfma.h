@@ -7,10 +7,15 @@
 // barrier per K-step) and are consumed as ds_read_b128 fragments:
 //   A row stride 36 floats (144 B): a 16-lane ds_read_b128 group hits 16 distinct 16-B slots;
 //   B rows are lane-contiguous.
+// A-tile loads are UNCONDITIONAL buffer loads: out-of-image taps get an out-of-range offset and
+// the buffer bounds check returns 0 (a per-chunk `ok ? load : 0` makes hipcc branch around every
+// load with an s_waitcnt in between, which serialises the loads and exposes their latency).
 // Per 8-wide k sub-step lanes 0-31 carry k-quad 2*kk, lanes 32-63 k-quad 2*kk+1, for A and B alike
 // (v_mfma_f32_32x32x2: lane l supplies k = l>>5), i.e. a fixed permutation of the K sum.
 // 4 waves (2 x 2); wave tile (BM/2) x (BN/2) = TM x TN MFMA tiles of 32 x 32.
 // Accumulator layout: lane owns output channel n = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Workgroup ids are remapped so that consecutive tiles (same pixel tile, neighbouring N tiles)
+// run on the same XCD and share its L2 (hardware places workgroup b on XCD b % 8).
 #pragma once
 #include "common.h"
 
@@ -37,6 +42,14 @@ struct ConvArgs {
 
 __device__ __forceinline__ float raft_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 raft_buffer_load_f4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0));
+}
+
+constexpr unsigned RAFT_OOB = 0x80000000u;   // >= any buffer extent we accept (< 2 GiB): load returns 0
+
 template <int KH, int KW, int BM, int BN, int EPI>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs p) {
     constexpr int BK = 32, LDA = 36;
@@ -49,27 +62,38 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
-    const int64_t M = (int64_t)p.B * p.H * p.W;
+    const int M = p.B * p.H * p.W;
     const int ntn = p.npad / BN;
-    const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
-    const int64_t m0 = (int64_t)mt * BM;
+
+    // XCD-aware remap (bijective for any grid size): logical tiles of one XCD are contiguous
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = bid / ntn, nt = bid - mt * ntn;
+    const int m0 = mt * BM;
     const int n0 = nt * BN;
     const int cin = p.c0 + p.c1;
     const int nch = cin / BK;
     const int S = KH * KW * nch;
 
+    // buffer descriptors of the two input sources (extent = last pixel's last used channel)
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.a0, 0, (int)((((long)M - 1) * p.lda0 + p.c0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.c1 ? p.a1 : p.a0), 0, p.c1 ? (int)((((long)M - 1) * p.lda1 + p.c1) * 4) : 0, 0x00020000);
+
     // A staging rows of this thread
     const int srow = tid >> 3, sc4 = tid & 7;
-    int py[NA], px[NA];
-    int64_t pm[NA];
-    bool pv[NA];
+    int py[NA], px[NA], pm[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int64_t m = m0 + srow + 32 * i;
-        pv[i] = m < M;
+        const int m = m0 + srow + 32 * i;
         pm[i] = m;
-        px[i] = (int)(m % p.W);
-        py[i] = (int)((m / p.W) % p.H);
+        px[i] = m % p.W;
+        py[i] = (m / p.W) % p.H;
+        if (m >= M) py[i] = -(1 << 20);          // row beyond M: every tap is out of range
     }
 
     f32x4 ra[NA], rb[NB];
@@ -77,26 +101,29 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs p) {
         const int t = s / nch, cc = s - t * nch;
         const int dy = t / KW - (KH - 1) / 2, dx = t % KW - (KW - 1) / 2;
         const int c = cc * BK;
-        const float *src;
-        int ld, ch;
-        if (c < p.c0) {
-            src = p.a0; ld = p.lda0; ch = c;
-        } else {
-            src = p.a1; ld = p.lda1; ch = c - p.c0;
-        }
+        const bool first = c < p.c0;
+        const int ld = first ? p.lda0 : p.lda1;
+        const int ch = (first ? c : c - p.c0) + sc4 * 4;
+        unsigned off[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int yy = py[i] + dy, xx = px[i] + dx;
-            const bool ok = pv[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[i] = ok ? *(const f32x4 *)(src + (pm[i] + (int64_t)dy * p.W + dx) * ld + ch + sc4 * 4) : z;
+            const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            off[i] = ok ? (unsigned)(((pm[i] + dy * p.W + dx) * ld + ch) * 4) : RAFT_OOB;
         }
-        const float *wsrc = p.wp + (((int64_t)t * (cin / 4) + c / 4) * p.npad + n0) * 4;
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = raft_buffer_load_f4(rs0, off[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = raft_buffer_load_f4(rs1, off[i]);
+        }
+        const float *wsrc = p.wp + (((long)t * (cin / 4) + c / 4) * p.npad + n0) * 4;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int q = tid + 256 * i;
             const int kq = q / BN, j = q - kq * BN;
-            rb[i] = *(const f32x4 *)(wsrc + ((int64_t)kq * p.npad + j) * 4);
+            rb[i] = *(const f32x4 *)(wsrc + ((long)kq * p.npad + j) * 4);
         }
     };
     auto lstore = [&](int buf) {
@@ -153,7 +180,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs p) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const long m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= M) continue;
                 const float v = acc[i][j][r] + bias;
                 if (EPI == EPI_LINEAR) {

@@ -157,10 +157,11 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = srow + 32 * i;
-            int ma = m0 + r, nb = n0 + r;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[i] = (ma < p.N) ? *(const f32x4 *)(A + (int64_t)ma * p.C + k0 + sc4 * 4) : z;
-            rb[i] = (nb < p.T) ? *(const f32x4 *)(Bm + (int64_t)nb * p.C + k0 + sc4 * 4) : z;
+            // rows beyond the edge are clamped, not branched around (their products are never stored):
+            // a conditional load becomes a branch + s_waitcnt per chunk and serialises the loads
+            const int ma = min(m0 + r, p.N - 1), nb = min(n0 + r, p.T - 1);
+            ra[i] = *(const f32x4 *)(A + (int64_t)ma * p.C + k0 + sc4 * 4);
+            rb[i] = *(const f32x4 *)(Bm + (int64_t)nb * p.C + k0 + sc4 * 4);
         }
     };
     auto lstore = [&](int buf) {
