@@ -44,8 +44,8 @@ def _worker(rank, world, port, total, tmp):
         import oracle
         from tf_raft_amd import weights as wm
         rng = np.random.default_rng(0)
-        i1 = rng.uniform(0, 255, (total, 32, 32, 3)).astype(np.float32)
-        i2 = rng.uniform(0, 255, (total, 32, 32, 3)).astype(np.float32)
+        i1 = rng.uniform(0, 255, (total, 64, 64, 3)).astype(np.float32)
+        i2 = rng.uniform(0, 255, (total, 64, 64, 3)).astype(np.float32)
         model = oracle.SmallRAFT(wm.init_weights('small', 0), iters_pred=2)
 
         def predict(inputs):
@@ -74,11 +74,11 @@ def test_two_rank_sharded_prediction_equals_single_process(tmp_path, total):
     import oracle
     from tf_raft_amd import weights as wm
     rng = np.random.default_rng(0)
-    i1 = rng.uniform(0, 255, (total, 32, 32, 3)).astype(np.float32)
-    i2 = rng.uniform(0, 255, (total, 32, 32, 3)).astype(np.float32)
+    i1 = rng.uniform(0, 255, (total, 64, 64, 3)).astype(np.float32)
+    i2 = rng.uniform(0, 255, (total, 64, 64, 3)).astype(np.float32)
     want = oracle.SmallRAFT(wm.init_weights('small', 0), iters_pred=2)([i1, i2])
     last = np.load(tmp_path / 'last.npy')
-    assert last.shape == (total, 32, 32, 2)
+    assert last.shape == (total, 64, 64, 2)
     np.testing.assert_allclose(last, want[-1], atol=1e-4)
     np.testing.assert_allclose(np.load(tmp_path / 'every1.npy'), want[1], atol=1e-4)
     assert int(np.load(tmp_path / 'n_every.npy')) == 2

@@ -7,6 +7,8 @@
 //                           staged in LDS, the (2r+1)^2 window is evaluated from it and written as
 //                           contiguous channels.              [reference corr.py:116-152, 28-69]
 //   raft_bilinear_sampler_f32, raft_coords_grid_f32           [reference corr.py:28-69, 72-90]
+#include <stdlib.h>
+
 #include "common.h"
 #include "lookup_common.h"
 
@@ -280,8 +282,80 @@ struct LookupArgs {
     int ld_out;
 };
 
+// v1 (default): the 2 x levels x (2r+1) axis taps {i0, i1, w0, w1} are evaluated ONCE per query by
+// 72 lanes and parked in LDS next to the footprint; every output then needs two 16-B tap reads,
+// four footprint reads and seven flops.  (v0 below recomputes four axis taps per output and is
+// VALU-issue bound; it is kept for A/B timing: RAFT_LOOKUP_V0=1.)
 template <int R>
 __global__ void __launch_bounds__(256) corr_lookup_kernel(LookupArgs p) {
+#pragma clang fp contract(off)   // keep mul/add unfused: same roundings as the unfused reference ops
+    constexpr int D = 2 * R + 1, FW = 2 * R + 2, FP = FW * FW, NT = RAFT_MAX_LEVELS * 2 * D;
+    __shared__ float sfp[4][RAFT_MAX_LEVELS][FP];
+    __shared__ __attribute__((aligned(16))) int stap[4][NT + 8][4];   // {i0 - origin, i1 - origin, w0, w1}
+    __shared__ int sorg[4][RAFT_MAX_LEVELS][2];                        // footprint origin (x, y) per level
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    const bool active = q < p.nq;
+    const int levels = p.g.levels;
+    float cx0 = 0.f, cy0 = 0.f;
+    if (active) {
+        cx0 = p.coords[2 * q];
+        cy0 = p.coords[2 * q + 1];
+        // ---- axis taps: entry t = (l*2 + axis)*D + d
+        for (int t = lane; t < levels * 2 * D; t += 64) {
+            const int l = t / (2 * D), r = t - l * (2 * D);
+            const int axis = r / D, d = r - axis * D;
+            const float sc = 1.0f / (float)(1 << l);   // exact power of two: x * sc == x / 2^l
+            const int size = axis ? p.g.lh[l] : p.g.lw[l];
+            const float c = (axis ? cy0 : cx0) * sc;
+            const AxisTap org = axis_tap(c, -R, size), tp = axis_tap(c, d - R, size);
+            stap[wave][t][0] = tp.i0 - org.i0;
+            stap[wave][t][1] = tp.i1 - org.i0;
+            stap[wave][t][2] = __float_as_int(tp.w0);
+            stap[wave][t][3] = __float_as_int(tp.w1);
+            if (d == 0) sorg[wave][l][axis] = org.i0;
+        }
+    }
+    __syncthreads();
+    if (active) {
+        // ---- footprint staging: (fy, fx) of this lane's two footprint slots do not depend on the level
+        const int i1 = lane + 64;
+        const int fy0 = lane / FW, fx0 = lane - fy0 * FW;
+        const int fy1 = i1 / FW, fx1 = i1 - fy1 * FW;
+#pragma unroll
+        for (int l = 0; l < RAFT_MAX_LEVELS; ++l) {
+            if (l >= levels) break;
+            const int w = p.g.lw[l], h = p.g.lh[l];
+            const int ox = sorg[wave][l][0], oy = sorg[wave][l][1];
+            const float *img = p.pyr + p.g.off[l] + q * ((int64_t)h * w);
+            sfp[wave][l][lane] = img[min(oy + fy0, h - 1) * w + min(ox + fx0, w - 1)];
+            if (i1 < FP) sfp[wave][l][i1] = img[min(oy + fy1, h - 1) * w + min(ox + fx1, w - 1)];
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const int nout = levels * D * D;
+    float *o = p.out + q * (int64_t)p.ld_out;
+    for (int c = lane; c < nout; c += 64) {
+        const int l = c / (D * D);
+        const int t = c - l * (D * D);
+        const int a = t / D, b = t - a * D;              // a offsets x, b offsets y (corr.py:133-143)
+        const int4 tx = *(const int4 *)stap[wave][(l * 2 + 0) * D + a];
+        const int4 ty = *(const int4 *)stap[wave][(l * 2 + 1) * D + b];
+        const float wx0 = __int_as_float(tx.z), wx1 = __int_as_float(tx.w);
+        const float wy0 = __int_as_float(ty.z), wy1 = __int_as_float(ty.w);
+        const float *f = sfp[wave][l];
+        const int y0 = ty.x * FW, y1 = ty.y * FW;
+        const float c00 = wy0 * wx0, c01 = wy0 * wx1, c10 = wy1 * wx0, c11 = wy1 * wx1;
+        float v = c00 * f[y0 + tx.x] + c01 * f[y0 + tx.y];
+        v = v + c10 * f[y1 + tx.x];
+        v = v + c11 * f[y1 + tx.y];
+        o[c] = v;
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) corr_lookup_v0_kernel(LookupArgs p) {
 #pragma clang fp contract(off)   // keep mul/add unfused: same roundings as the unfused reference ops
     constexpr int D = 2 * R + 1, FW = 2 * R + 2, FP = FW * FW;
     __shared__ float sfp[4][RAFT_MAX_LEVELS][FP];
@@ -352,12 +426,21 @@ extern "C" int raft_corr_lookup_f32(const float *pyr, const int64_t *level_offse
     a.ld_out = ld_out;
     const int blocks = raft_ceil_div(a.nq, 4);
     hipStream_t s = (hipStream_t)stream;
-    if (radius == 4)
-        corr_lookup_kernel<4><<<blocks, 256, 0, s>>>(a);
-    else if (radius == 3)
-        corr_lookup_kernel<3><<<blocks, 256, 0, s>>>(a);
-    else
+    const char *v0 = getenv("RAFT_LOOKUP_V0");   // A/B timing switch only
+    const bool use_v0 = v0 && v0[0] == '1';
+    if (radius == 4) {
+        if (use_v0)
+            corr_lookup_v0_kernel<4><<<blocks, 256, 0, s>>>(a);
+        else
+            corr_lookup_kernel<4><<<blocks, 256, 0, s>>>(a);
+    } else if (radius == 3) {
+        if (use_v0)
+            corr_lookup_v0_kernel<3><<<blocks, 256, 0, s>>>(a);
+        else
+            corr_lookup_kernel<3><<<blocks, 256, 0, s>>>(a);
+    } else {
         return RAFT_E_UNSUPPORTED;
+    }
     return raft_launch_status();
 }
 

@@ -1,0 +1,85 @@
+"""Run ONE kernel configuration repeatedly (for rocprofv3 --pmc passes and A/B timing on the GPU box).
+
+  python tools/one_kernel.py conv <layer> <tile|auto> [B] [reps]
+  python tools/one_kernel.py lookup <v0|v1> [B] [reps]
+Prints the HIP-event average per launch.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tf_raft_amd import _dev, packing          # noqa: E402
+from tf_raft_amd._ffi import check             # noqa: E402
+
+LAYERS = {  # name: kh, kw, cin(real), cin(pad), cout
+    'convc1': (1, 1, 324, 352, 256), 'convc2': (3, 3, 256, 256, 192), 'convf2': (3, 3, 128, 128, 64),
+    'conv': (3, 3, 256, 256, 126), 'gru_zr': (1, 5, 384, 384, 256), 'gru_q': (1, 5, 384, 384, 128),
+    'gru_zr_v': (5, 1, 384, 384, 256), 'fh1_mask0': (3, 3, 128, 128, 512), 'mask2': (1, 1, 256, 256, 576)}
+H, W = 56, 64
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    kind = sys.argv[1]
+    rng = np.random.default_rng(0)
+    lib = _dev.lib()
+    if kind == 'conv':
+        name, tile = sys.argv[2], sys.argv[3]
+        B = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+        reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+        kh, kw, cin, cpad, cout = LAYERS[name]
+        if tile != 'auto':
+            os.environ['RAFT_CONV_TILE'] = tile
+        k = (rng.normal(size=(kh, kw, cin, cout)) * 0.05).astype(np.float32)
+        wp, b, npad = packing.pack_conv(k, np.zeros(cout, np.float32), [(cin, cpad)])
+        x = _dev.to_device(rng.normal(size=(B, H, W, cpad)).astype(np.float32))
+        wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
+        out = torch.empty((B, H, W, cout), device=x.device)
+
+        def run():
+            check(lib.raft_conv2d_f32(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W,
+                                      kh, kw, npad, cout, 1, 1.0, _dev.ptr(out), cout, _dev.stream_ptr()))
+        ms = timed(run, reps)
+        flops = 2.0 * B * H * W * kh * kw * cin * cout
+        print(f'conv {name} tile={tile} B={B}: {ms*1e3:.1f} us  {flops / ms / 1e9:.1f} TFLOP/s')
+    elif kind == 'lookup':
+        ver = sys.argv[2]
+        B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+        reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+        if ver == 'v0':
+            os.environ['RAFT_LOOKUP_V0'] = '1'
+        from tf_raft_amd.layers.corr import CorrBlock
+        f1 = rng.normal(size=(B, H, W, 256)).astype(np.float32)
+        f2 = rng.normal(size=(B, H, W, 256)).astype(np.float32)
+        corr = CorrBlock(f1, f2, 4, 4)
+        ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+        coords = np.stack([xs, ys], -1)[None].repeat(B, 0) + rng.normal(scale=6.0, size=(B, H, W, 2)).astype(np.float32)
+        coords_d = _dev.to_device(coords)
+        out = torch.empty((B, H, W, 352), device=coords_d.device)
+
+        def run():
+            corr.retrieve(coords_d, out=out, ld_out=352)
+        ms = timed(run, reps)
+        bytes_ = B * H * W * (4 * 100 * 4 + 8 + 324 * 4)
+        print(f'lookup {ver} B={B}: {ms*1e3:.1f} us  {bytes_ / ms / 1e6:.0f} GB/s algorithmic')
+    else:
+        raise SystemExit(__doc__)
+
+
+if __name__ == '__main__':
+    main()
