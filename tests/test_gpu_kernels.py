@@ -225,7 +225,7 @@ def _conv_device(x_srcs, kernel, bias, act, scale=1.0, nvalid=None):
     return _np(out)
 
 
-@pytest.mark.parametrize('tile', ['128128', '064128', '128064', '064064'])
+@pytest.mark.parametrize('tile', ['0', '1', '2', '3', '4', '5', '141', '142', '171', '172', '181', '182'])   # conv.hip tile codes
 @pytest.mark.parametrize('ksize', [(1, 1), (3, 3), (1, 5), (5, 1)])
 def test_conv2d_mfma_matches_oracle(rng, ksize, tile):
     from oracle import tf_ops
@@ -314,6 +314,33 @@ def test_small_update_block_matches_oracle(rng, shape):
         err = float(np.abs(_np(g) - r.numpy()).max())
         report(f'small_update{shape} {name}', hip_vs_f64=err)
         assert err < tol
+
+
+@pytest.mark.parametrize('variant', ['raft', 'small'])
+@pytest.mark.parametrize('tile', ['0', '1', '2', '3', '4', '5', '141', '142', '171', '172', '181', '182'])
+def test_update_blocks_every_conv_tile(rng, variant, tile):
+    """GRU / relu / linear epilogues of every instantiated tile (forced through RAFT_CONV_TILE where the
+    tile divides the layer's npad), M = 2*9*13 = 234 pixels: M tails of the 64/112/128-row tiles."""
+    from oracle.layers import W, basic_update_block, small_update_block
+    from tf_raft_amd import weights as wm
+    from tf_raft_amd.layers.update import BasicUpdateBlock, SmallUpdateBlock
+    B, h, w = 2, 9, 13
+    wts = wm.init_weights(variant, seed=6, perturb=True)
+    net, inp, corr, flow = _update_inputs(rng, variant, B, h, w)
+    blk = (BasicUpdateBlock(filters=128, weights=wts) if variant == 'raft' else SmallUpdateBlock(filters=96, weights=wts))
+    os.environ['RAFT_CONV_TILE'] = tile
+    try:
+        gn, gm, gd = blk([net, inp, corr, flow])
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop('RAFT_CONV_TILE', None)
+    fn = basic_update_block if variant == 'raft' else small_update_block
+    rn, rm, rd = fn(W(wts, torch.float64), 'update_block', *[_t(a).double() for a in (net, inp, corr, flow)])
+    errs = dict(net=float(np.abs(_np(gn) - rn.numpy()).max()), delta=float(np.abs(_np(gd) - rd.numpy()).max()))
+    if gm is not None:
+        errs['mask'] = float(np.abs(_np(gm) - rm.numpy()).max())
+    report(f'update {variant} tile {tile}', **errs)
+    assert errs['net'] < 2e-5 and errs['delta'] < 5e-5 and errs.get('mask', 0.0) < 5e-5
 
 
 def test_update_block_rejects_wrong_shapes(rng):

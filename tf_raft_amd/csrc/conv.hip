@@ -1,84 +1,141 @@
 // Convolution launchers, the two small special convolutions, and the BasicUpdateBlock sequencing
 // (reference tf_raft/layers/update.py:5-153, tf_raft/model.py:84-109) for gfx950.
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
-#include "conv_mfma.h"
+#include "conv_halo.h"
 
 // ------------------------------------------------------------------------------------------------
 // tile selection + dispatch of the implicit-GEMM kernel
 // ------------------------------------------------------------------------------------------------
+struct TileInfo {
+    int mf, bm, bn;
+    int lds_bytes;
+};
+static const TileInfo kTiles[TILE_COUNT] = {
+    {32, 128, 128, 2 * (128 * 36 + 32 * 128) * 4}, {32, 64, 128, 2 * (64 * 36 + 32 * 128) * 4},
+    {32, 128, 64, 2 * (128 * 36 + 32 * 64) * 4},   {32, 64, 64, 2 * (64 * 36 + 32 * 64) * 4},
+    {16, 112, 128, 2 * (128 * 40 + 32 * 128) * 4}, {16, 112, 64, 2 * (128 * 40 + 32 * 64) * 4},
+};
+
 template <int KH, int KW, int EPI>
-static int launch_conv_tiles(const ConvArgs &a, int bm, int bn, hipStream_t s) {
+static int launch_conv_tile(const ConvArgs &a, int tile, hipStream_t s) {
     const int64_t M = (int64_t)a.B * a.H * a.W;
-    const int grid = raft_ceil_div(M, bm) * (a.npad / bn);
-    if (bm == 128 && bn == 128)
-        conv_mfma_kernel<KH, KW, 128, 128, EPI><<<grid, 256, 0, s>>>(a);
-    else if (bm == 64 && bn == 128)
-        conv_mfma_kernel<KH, KW, 64, 128, EPI><<<grid, 256, 0, s>>>(a);
-    else if (bm == 128 && bn == 64)
-        conv_mfma_kernel<KH, KW, 128, 64, EPI><<<grid, 256, 0, s>>>(a);
-    else
-        conv_mfma_kernel<KH, KW, 64, 64, EPI><<<grid, 256, 0, s>>>(a);
+    const TileInfo &t = kTiles[tile];
+    const int grid = raft_ceil_div(M, t.bm) * (a.npad / t.bn);
+    switch (tile) {
+        case TILE_32_128x128: conv_mfma_kernel<KH, KW, 32, 128, 128, 2, 2, EPI><<<grid, 256, 0, s>>>(a); break;
+        case TILE_32_64x128: conv_mfma_kernel<KH, KW, 32, 64, 128, 2, 2, EPI><<<grid, 256, 0, s>>>(a); break;
+        case TILE_32_128x64: conv_mfma_kernel<KH, KW, 32, 128, 64, 2, 2, EPI><<<grid, 256, 0, s>>>(a); break;
+        case TILE_32_64x64: conv_mfma_kernel<KH, KW, 32, 64, 64, 2, 2, EPI><<<grid, 256, 0, s>>>(a); break;
+        case TILE_16_112x128: conv_mfma_kernel<KH, KW, 16, 112, 128, 1, 4, EPI><<<grid, 256, 0, s>>>(a); break;
+        case TILE_16_112x64: conv_mfma_kernel<KH, KW, 16, 112, 64, 1, 4, EPI><<<grid, 256, 0, s>>>(a); break;
+        default: return RAFT_E_UNSUPPORTED;
+    }
     return raft_launch_status();
 }
 
 template <int KH, int KW>
-static int launch_conv_epi(const ConvArgs &a, int epi, int bm, int bn, hipStream_t s) {
+static int launch_conv_epi(const ConvArgs &a, int epi, int tile, hipStream_t s) {
     switch (epi) {
-        case EPI_LINEAR: return launch_conv_tiles<KH, KW, EPI_LINEAR>(a, bm, bn, s);
-        case EPI_RELU: return launch_conv_tiles<KH, KW, EPI_RELU>(a, bm, bn, s);
-        case EPI_GRU_ZR: return launch_conv_tiles<KH, KW, EPI_GRU_ZR>(a, bm, bn, s);
-        case EPI_GRU_Q: return launch_conv_tiles<KH, KW, EPI_GRU_Q>(a, bm, bn, s);
+        case EPI_LINEAR: return launch_conv_tile<KH, KW, EPI_LINEAR>(a, tile, s);
+        case EPI_RELU: return launch_conv_tile<KH, KW, EPI_RELU>(a, tile, s);
+        case EPI_GRU_ZR: return launch_conv_tile<KH, KW, EPI_GRU_ZR>(a, tile, s);
+        case EPI_GRU_Q: return launch_conv_tile<KH, KW, EPI_GRU_Q>(a, tile, s);
     }
     return RAFT_E_UNSUPPORTED;
 }
 
-// Pick the output tile that minimises (workgroups per CU, rounded up) x (tile cost).  MI355X has
-// 256 CUs; smaller tiles balance better but stage more bytes per MFMA (cost factors below are the
-// measured relative per-MAC costs).
-static void pick_tile(int64_t M, int npad, int *bm, int *bn) {
-    const char *env = getenv("RAFT_CONV_TILE");   // tuning / test override, e.g. 128064 = BM 128, BN 64
-    const int forced = env ? atoi(env) : 0;
-    if (forced) {
-        int fbm = forced / 1000, fbn = forced % 1000;
-        if ((fbm == 64 || fbm == 128) && (fbn == 64 || fbn == 128) && npad % fbn == 0) {
-            *bm = fbm;
-            *bn = fbn;
-            return;
-        }
+// Tuning / test override: RAFT_CONV_TILE is either one code (applies to every convolution whose npad
+// it divides) or a comma-separated list of `npad:taps:code` entries, e.g. "256:5:171,128:5:141".
+// code 0..5 = legacy (tap, chunk)-stepped tiles (ConvTile); 100 + 10*TH + TN = halo-tiled kernel.
+static bool code_valid(int code, int npad) {
+    if (code >= 0 && code < TILE_COUNT) return npad % kTiles[code].bn == 0;
+    if (code >= 100) {
+        const int th = (code - 100) / 10, tn = (code - 100) % 10;
+        return (th == 4 || th == 7 || th == 8) && (tn == 1 || tn == 2) && npad % (64 * tn) == 0;
     }
-    const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-    const double cost[4] = {1.00, 1.06, 1.06, 1.14};
+    return false;
+}
+static int forced_code(int npad, int taps) {
+    const char *env = getenv("RAFT_CONV_TILE");
+    if (!env || !*env) return -1;
+    if (!strchr(env, ':')) {
+        const int t = atoi(env);
+        return code_valid(t, npad) ? t : -1;
+    }
+    const char *p = env;
+    while (*p) {
+        int n = 0, k = 0, t = 0;
+        if (sscanf(p, "%d:%d:%d", &n, &k, &t) == 3 && n == npad && k == taps && code_valid(t, npad)) return t;
+        p = strchr(p, ',');
+        if (!p) break;
+        ++p;
+    }
+    return -1;
+}
+
+// Pick the halo tile (TH x 16 pixels, 64*TN channels) by a small cost model of MI355X (256 CUs):
+//   time ~ (workgroups per CU, rounded up) x (MFMA work of one tile) x (latency-hiding penalty),
+// where the penalty reflects how many workgroups (= waves per SIMD) are co-resident on a CU: one wave
+// per SIMD exposes prologue / barrier / epilogue latency, three or more hide it.
+static int pick_code(const ConvArgs &a, int kh, int kw) {
+    const int f = forced_code(a.npad, kh * kw);
+    if (f >= 0) return f;
+    static const int ths[3] = {4, 7, 8};
     double best = 1e30;
-    for (int i = 0; i < 4; ++i) {
-        const int cbm = cand[i][0], cbn = cand[i][1];
-        if (npad % cbn) continue;
-        const int64_t blocks = ((M + cbm - 1) / cbm) * (npad / cbn);
-        const double t = (double)((blocks + 255) / 256) * cbm * cbn * cost[i];
-        if (t < best) {
-            best = t;
-            *bm = cbm;
-            *bn = cbn;
+    int best_code = 141;
+    for (int ti = 0; ti < 3; ++ti)
+        for (int tn = 1; tn <= 2; ++tn) {
+            const int th = ths[ti];
+            if (a.npad % (64 * tn)) continue;
+            const int64_t blocks = (int64_t)a.B * ((a.H + th - 1) / th) * ((a.W + 15) / 16) * (a.npad / (64 * tn));
+            const int64_t per_cu = (blocks + 255) / 256;
+            const int lds = 2 * ((th + kh - 1) * (16 + kw - 1) * 40 + 8) * 4;
+            int resident = 160 * 1024 / lds;
+            const int reg_limit = (tn == 2 && th >= 7) ? 1 : (th >= 7 ? 2 : 3);   // VGPR + AGPR budget per SIMD
+            if (resident > reg_limit) resident = reg_limit;
+            const int64_t conc = per_cu < resident ? per_cu : resident;
+            const double pen = conc >= 3 ? 1.0 : (conc == 2 ? 1.05 : 1.15);
+            const double eff = th == 4 ? 0.88 : 1.0;   // short tiles: more halo and weight traffic per MFMA (measured)
+            const double cost = (double)per_cu * th * 16 * 64 * tn * pen / eff;
+            if (cost < best) {
+                best = cost;
+                best_code = 100 + th * 10 + tn;
+            }
         }
-    }
+    return best_code;
 }
 
 int raft_launch_conv(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s) {
     if (a.c0 <= 0 || a.c0 % 32 || a.c1 < 0 || a.c1 % 32 || a.npad <= 0 || a.npad % 64) return RAFT_E_UNSUPPORTED;
     if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
     if (!raft_aligned16(a.a0) || !raft_aligned16(a.wp) || (a.c1 && !raft_aligned16(a.a1))) return RAFT_E_ALIGN;
-    {   // the A tiles are fetched through 32-bit buffer offsets: each source must span < 2 GiB
+    {   // every operand is addressed through 32-bit buffer offsets: each must span < 2 GiB
         const int64_t M = (int64_t)a.B * a.H * a.W;
+        const int64_t lim = (int64_t)1 << 31;
         const int64_t e0 = ((M - 1) * a.lda0 + a.c0) * 4, e1 = a.c1 ? ((M - 1) * a.lda1 + a.c1) * 4 : 0;
-        if (e0 >= (int64_t)1 << 31 || e1 >= (int64_t)1 << 31) return RAFT_E_UNSUPPORTED;
+        if (e0 >= lim || e1 >= lim) return RAFT_E_UNSUPPORTED;
+        if (M * a.ldo0 * 4 >= lim || (a.o1 && M * a.ldo1 * 4 >= lim) || (a.e0 && M * a.lde0 * 4 >= lim) ||
+            (a.e1 && M * a.lde1 * 4 >= lim))
+            return RAFT_E_UNSUPPORTED;
+        if ((int64_t)kh * kw * (a.c0 + a.c1) * a.npad * 4 >= lim) return RAFT_E_UNSUPPORTED;
     }
-    int bm = 64, bn = 64;
-    pick_tile((int64_t)a.B * a.H * a.W, a.npad, &bm, &bn);
-    if (kh == 1 && kw == 1) return launch_conv_epi<1, 1>(a, epi, bm, bn, s);
-    if (kh == 3 && kw == 3) return launch_conv_epi<3, 3>(a, epi, bm, bn, s);
-    if (kh == 1 && kw == 5) return launch_conv_epi<1, 5>(a, epi, bm, bn, s);
-    if (kh == 5 && kw == 1) return launch_conv_epi<5, 1>(a, epi, bm, bn, s);
-    return RAFT_E_UNSUPPORTED;
+    const bool known = (kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 1 && kw == 5) || (kh == 5 && kw == 1);
+    if (!known) return RAFT_E_UNSUPPORTED;
+    const int code = pick_code(a, kh, kw);
+    if (code >= 100) {
+        const int th = (code - 100) / 10, tn = (code - 100) % 10;
+        if (kh == 1 && kw == 1) return raft_launch_conv_halo_1x1(a, th, tn, epi, s);
+        if (kh == 3 && kw == 3) return raft_launch_conv_halo_3x3(a, th, tn, epi, s);
+        if (kh == 1 && kw == 5) return raft_launch_conv_halo_1x5(a, th, tn, epi, s);
+        return raft_launch_conv_halo_5x1(a, th, tn, epi, s);
+    }
+    if (kh == 1 && kw == 1) return launch_conv_epi<1, 1>(a, epi, code, s);
+    if (kh == 3 && kw == 3) return launch_conv_epi<3, 3>(a, epi, code, s);
+    if (kh == 1 && kw == 5) return launch_conv_epi<1, 5>(a, epi, code, s);
+    return launch_conv_epi<5, 1>(a, epi, code, s);
 }
 
 extern "C" int raft_conv2d_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,

@@ -29,11 +29,11 @@ for name, kh, kw, cin, cpad, cout in LAYERS:
     out = torch.empty((B, H, W, cout), device=x.device)
     flops = 2.0 * B * H * W * kh * kw * cin * cout
     row = []
-    for tile in ('128128', '064128', '128064', '064064', 'auto'):
+    for tile in ('3', '5', '141', '142', '171', '172', '181', '182', 'auto'):
         if tile == 'auto':
             os.environ.pop('RAFT_CONV_TILE', None)
         else:
-            if npad % int(tile[3:]):
+            if npad % ({'3': 64, '5': 64}.get(tile) or 64 * int(tile[-1])):
                 row.append(f'{tile}:   n/a')
                 continue
             os.environ['RAFT_CONV_TILE'] = tile
