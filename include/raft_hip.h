@@ -188,6 +188,37 @@ int raft_iterate_basic_timed_f32(const raft_basic_update_weights *wts, const flo
                                  const raft_state *st, float *flow_up, void *stream,
                                  float *stage_ms /* host, [RAFT_BASIC_STAGES] */);
 
+/* ------------------------------------------------------------------ encoders */
+
+/* BasicEncoder / SmallEncoder forward (reference extractor.py:88-130, 133-175; ResBlock 19-49;
+ * Normalization 6-16), inference mode.  Channel widths: stem c0, layer1..3 c1..c3 (multiples of 32),
+ * output cout.  norm:
+ *   RAFT_NORM_NONE      no normalisation (SmallRAFT cnet)
+ *   RAFT_NORM_INSTANCE  tfa InstanceNormalization, eps 1e-3, biased variance, affine in_gamma / in_beta
+ *   RAFT_NORM_FOLDED    Keras BatchNormalization in inference mode, folded into kernels and biases by the
+ *                       host packer (tf_raft_amd/packing.py): the device sees plain convolutions
+ * Convolution kernels use the packed layout above; the 7x7 stem is packed as 7 K-chunks (one per kernel
+ * row) of k = kx * 4 + ch over the 4-channel padded image.  block[i][2] (down-sampling 1x1) has wp == NULL
+ * for stride-1 blocks.  in_gamma / in_beta index: 0 = stem norm1, 1 + 3*i + {0, 1, 2} = block i norm1,
+ * norm2, downsample norm. */
+enum { RAFT_NORM_NONE = 0, RAFT_NORM_INSTANCE = 1, RAFT_NORM_FOLDED = 2 };
+
+typedef struct raft_encoder_weights {
+    int c0, c1, c2, c3, cout, norm;
+    raft_conv_weights conv1;
+    raft_conv_weights block[6][3];
+    raft_conv_weights conv2;
+    const float *in_gamma[19];
+    const float *in_beta[19];
+} raft_encoder_weights;
+
+int64_t raft_encoder_workspace_floats(const raft_encoder_weights *w, int n, int H, int W);
+
+/* images: (n, H, W, 3); out: (n, ceil(H/8), ceil(W/8), cout).  input_affine != 0 applies the model's
+ * 2 * (image / 255) - 1 (reference model.py:70-71) while the image is staged. */
+int raft_encoder_f32(const raft_encoder_weights *w, const float *images, int n, int H, int W,
+                     int input_affine, float *out, float *workspace, void *stream);
+
 /* ------------------------------------------------------------------ SmallRAFT update block */
 
 /* SmallUpdateBlock weights (reference update.py:109-125): z and r of the 3x3 ConvGRU fused along N

@@ -33,6 +33,15 @@ class SmallUpdateWeights(C.Structure):
         'convc1', 'convf1', 'convf2', 'conv', 'gru_zr', 'gru_q', 'fh1', 'fh2')]
 
 
+class EncoderWeights(C.Structure):
+    _fields_ = [('c0', C.c_int), ('c1', C.c_int), ('c2', C.c_int), ('c3', C.c_int), ('cout', C.c_int),
+                ('norm', C.c_int), ('conv1', ConvWeights), ('block', (ConvWeights * 3) * 6), ('conv2', ConvWeights),
+                ('in_gamma', C.c_void_p * 19), ('in_beta', C.c_void_p * 19)]
+
+
+NORM_NONE, NORM_INSTANCE, NORM_FOLDED = 0, 1, 2
+
+
 class State(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'net', 'x', 'corr', 'coords1', 'flow', 'delta', 'mask', 'ws')]
@@ -62,6 +71,8 @@ _SIGNATURES = {
                                     C.POINTER(State), _P, _P]),
     'raft_iterate_basic_timed_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
                                           C.POINTER(State), _P, _P, C.POINTER(C.c_float)]),
+    'raft_encoder_workspace_floats': (C.c_int64, [C.POINTER(EncoderWeights), _I, _I, _I]),
+    'raft_encoder_f32': (_I, [C.POINTER(EncoderWeights), _P, _I, _I, _I, _I, _P, _P, _P]),
     'raft_small_update_workspace_floats': (C.c_int64, [_I, _I, _I]),
     'raft_prepare_state_small_f32': (_I, [_P, _I, _I, _I, C.POINTER(State), _P]),
     'raft_update_small_f32': (_I, [C.POINTER(SmallUpdateWeights), _I, _I, _I, C.POINTER(State), _P]),

@@ -19,6 +19,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (!(cond)) return (code); \
     } while (0)
 
+#define RAFT_TRY(expr)              \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != RAFT_OK) return rc__; \
+    } while (0)
+
 // Launch-error check: hipError_t values are positive, RAFT_E_* negative, RAFT_OK == hipSuccess == 0.
 static inline int raft_launch_status() { return (int)hipGetLastError(); }
 

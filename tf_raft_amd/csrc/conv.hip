@@ -108,7 +108,14 @@ static int pick_code(const ConvArgs &a, int kh, int kw) {
     return best_code;
 }
 
-int raft_launch_conv(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s) {
+int raft_launch_conv(const ConvArgs &a_in, int kh, int kw, int epi, hipStream_t s) {
+    ConvArgs a = a_in;
+    if (a.Hi == 0) {   // plain stride-1 'same' convolution
+        a.Hi = a.H;
+        a.Wi = a.W;
+        a.pt = (kh - 1) / 2;
+        a.pl = (kw - 1) / 2;
+    }
     if (a.c0 <= 0 || a.c0 % 32 || a.c1 < 0 || a.c1 % 32 || a.npad <= 0 || a.npad % 64) return RAFT_E_UNSUPPORTED;
     if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
     if (!raft_aligned16(a.a0) || !raft_aligned16(a.wp) || (a.c1 && !raft_aligned16(a.a1))) return RAFT_E_ALIGN;
@@ -359,12 +366,6 @@ static ConvArgs conv_args(const raft_conv_weights &wt, const float *a0, int lda0
     a.B = B; a.H = h; a.W = w; a.scale = 1.0f; a.o0 = o0; a.ldo0 = ldo0;
     return a;
 }
-
-#define RAFT_TRY(expr)              \
-    do {                            \
-        int rc__ = (expr);          \
-        if (rc__ != RAFT_OK) return rc__; \
-    } while (0)
 
 // Optional per-stage HIP-event recorder (profiling entry point only; see raft_iterate_basic_timed_f32).
 struct StageTimer {

@@ -30,21 +30,35 @@
 #pragma once
 #include "conv_mfma.h"
 
-template <int KH, int KW, int TH, int TN, int EPI>
+// Template parameters beyond the tile shape:
+//   STRIDE 1 | 2   output stride (encoder down-sampling convolutions, TF 'SAME'/'valid' padding via p.pt/p.pl);
+//                  for 1x1 kernels the stride is applied while staging (only the needed pixels are fetched)
+//   PRE            the input is relu(x * scale[b][c] + shift[b][c]) applied while staging the halo tile
+//                  (= instance norm + relu of the producer fused into the consumer); padding stays zero
+//   STATS          also write per-tile (sum, sum of squares) of the raw output per channel (instance-norm moments)
+//   STEM           7x7 stride-2 stem on a 4-channel-padded image: K chunk c = kernel row c, k = (kx, ch) of the
+//                  7 x 4 input window (+ 4 zero columns); KH = KW = 1 and cin = 7 * 32 in this mode
+template <int KH, int KW, int TH, int TN, int EPI, int STRIDE = 1, int PRE = 0, int STATS = 0, int STEM = 0>
 __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
-    constexpr int TW = 16, LDA = 40, NKK = 2;
-    constexpr int HH = TH + KH - 1, HWP = TW + KW - 1, HP = HH * HWP;   // halo tile
-    constexpr int NA = (HP * 8 + 255) / 256;                            // float4 chunks per thread per K chunk
-    constexpr int A_BUF = HP * LDA + 8;                                 // + one dummy 16-byte slot for padding items
-    constexpr int BN = 64 * TN;
+    constexpr int TW = 16, NKK = 2;
     constexpr int TAPS = KH * KW, R = TAPS * NKK;
+    constexpr int LSTEP = (TAPS == 1 && !STEM) ? STRIDE : 1;   // input pixels between neighbouring halo pixels
+    constexpr int FSTEP = (TAPS == 1) ? 1 : STRIDE;            // halo pixels between neighbouring output pixels
+    constexpr int LDA = (FSTEP == 2) ? 36 : 40;                // conflict-free pixel-row stride (tools/bank_check.py)
+    constexpr int HH = (TH - 1) * FSTEP + KH, HWP = (TW - 1) * FSTEP + KW, HP = HH * HWP;   // halo tile
+    constexpr int NA = (HP * 8 + 255) / 256;                   // float4 chunks per thread per K chunk
+    constexpr int A_BUF = HP * LDA + 8;                        // + one dummy 16-byte slot for padding items
+    constexpr int BN = 64 * TN;
+    static_assert(!STEM || (TAPS == 1 && STRIDE == 2 && !PRE), "stem mode: 1x1 addressing, stride 2");
     __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int G = lane >> 4, LR = lane & 15;
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int ntn = p.npad / BN;
-    const int M = p.B * p.H * p.W;
+    const int M = p.B * p.H * p.W;                     // output pixels
+    const int Hi = p.Hi, Wi = p.Wi;
+    const int Min = p.B * Hi * Wi;                     // input pixels
 
     // XCD-aware remap (bijective for any grid size): logical tiles of one XCD are contiguous, and the
     // N tiles of one pixel tile are neighbours, so they share the halo tile in that XCD's L2
@@ -61,27 +75,44 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
     const int nch = cin >> 5;
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)p.a0, 0, (int)((((long)M - 1) * p.lda0 + p.c0) * 4), 0x00020000);
+        (void *)p.a0, 0, (int)((((long)Min - 1) * p.lda0 + (STEM ? 4 : p.c0)) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.c1 ? p.a1 : p.a0), 0, p.c1 ? (int)((((long)M - 1) * p.lda1 + p.c1) * 4) : 0, 0x00020000);
+        (void *)(p.c1 ? p.a1 : p.a0), 0, p.c1 ? (int)((((long)Min - 1) * p.lda1 + p.c1) * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.wp, 0, (int)((long)TAPS * cin * p.npad * 4), 0x00020000);
 
     // ---- halo staging assignment: item = (halo pixel, 16-byte channel quad)
-    int pix[NA];          // image pixel index of the item's halo pixel, or -1 (outside the image / padding item)
+    int pix[NA];          // input pixel index of the item's halo pixel, or -1 (outside the image / padding item)
     int lds_off[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int item = tid + 256 * i;
         const int hp = item >> 3, c4 = item & 7;
         const int hy = hp / HWP, hx = hp - hy * HWP;
-        const int yy = y0 + hy - (KH - 1) / 2, xx = x0 + hx - (KW - 1) / 2;
-        const bool ok = (hp < HP) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
-        pix[i] = ok ? (b * p.H + yy) * p.W + xx : -1;
         lds_off[i] = hp < HP ? hp * LDA + c4 * 4 : HP * LDA;
+        if (STEM) {
+            // pix = input pixel of kernel column c4 in kernel row 0; the row is advanced per chunk in gload()
+            const int yy = (y0 + hy) * 2 - p.pt, xx = (x0 + hx) * 2 - p.pl + c4;
+            const bool ok = (hp < HP) & (c4 < 7) & ((unsigned)xx < (unsigned)Wi);
+            pix[i] = ok ? (b * Hi + yy) * Wi + xx : -(1 << 30);    // yy may still be out of range: checked per chunk
+        } else {
+            const int yy = y0 * STRIDE - p.pt + hy * LSTEP, xx = x0 * STRIDE - p.pl + hx * LSTEP;
+            const bool ok = (hp < HP) & ((unsigned)yy < (unsigned)Hi) & ((unsigned)xx < (unsigned)Wi);
+            pix[i] = ok ? (b * Hi + yy) * Wi + xx : -1;
+        }
     }
-    f32x4 ra[NA];
+    f32x4 ra[NA], pre_sc, pre_sh;
     auto gload = [&](int c) {
+        if (STEM) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int hp = (tid + 256 * i) >> 3;
+                const int yy = (y0 + hp / HWP) * 2 - p.pt + c;                   // kernel row c
+                const bool ok = (pix[i] > -(1 << 29)) & ((unsigned)yy < (unsigned)Hi);
+                ra[i] = raft_buffer_load_f4(rs0, ok ? (unsigned)((pix[i] + c * Wi) * 16) : RAFT_OOB);
+            }
+            return;
+        }
         const int ch = c * 32;
         const bool first = ch < p.c0;
         const int ld = first ? p.lda0 : p.lda1;
@@ -95,21 +126,32 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
             for (int i = 0; i < NA; ++i)
                 ra[i] = raft_buffer_load_f4(rs1, pix[i] >= 0 ? (unsigned)((pix[i] * ld + chl) * 4) : RAFT_OOB);
         }
+        if (PRE) {
+            pre_sc = *(const f32x4 *)(p.pre_scale + (long)b * cin + ch + (tid & 7) * 4);
+            pre_sh = *(const f32x4 *)(p.pre_shift + (long)b * cin + ch + (tid & 7) * 4);
+        }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *(f32x4 *)(smem + buf * A_BUF + lds_off[i]) = ra[i];
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v = ra[i];
+            if (PRE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pix[i] >= 0 ? fmaxf(fmaf(v[e], pre_sc[e], pre_sh[e]), 0.f) : 0.f;
+            }
+            *(f32x4 *)(smem + buf * A_BUF + lds_off[i]) = v;
+        }
     };
 
     // ---- fragment fetch
     f32x4 fa[2][TH], fb[2][TN];
-    const int a_lane = LR * LDA + G * 4;                                  // + window shift + kk*16
+    const int a_lane = LR * FSTEP * LDA + G * 4;                          // + window shift + kk*16
     const unsigned b_lane = (unsigned)(((G * p.npad) + n0 + wn * 16 * TN + LR) * 16);   // bytes
     auto frag_a = [&](int buf, int q, f32x4 *a) {
         const int t = q / NKK, kk = q - t * NKK;
         const float *base = smem + buf * A_BUF + a_lane + ((t / KW) * HWP + (t % KW)) * LDA + kk * 16;
 #pragma unroll
-        for (int i = 0; i < TH; ++i) a[i] = *(const f32x4 *)(base + i * HWP * LDA);
+        for (int i = 0; i < TH; ++i) a[i] = *(const f32x4 *)(base + i * FSTEP * HWP * LDA);
     };
     auto frag_b = [&](int c, int q, f32x4 *bf) {
         const int t = q / NKK, kk = q - t * NKK;
@@ -168,7 +210,7 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
         (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + w0) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(w1 > 0 ? p.o1 : p.o0), 0, w1 > 0 ? (int)((((long)M - 1) * p.ldo1 + w1) * 4) : 0, 0x00020000);
-    const bool has_e0 = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q, has_e1 = EPI == EPI_GRU_Q;
+    const bool has_e0 = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q || EPI == EPI_RES, has_e1 = EPI == EPI_GRU_Q;
     const int we = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;
     const __amdgpu_buffer_rsrc_t re0 = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(has_e0 ? (const void *)p.e0 : (const void *)p.o0), 0,
@@ -182,9 +224,13 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
     auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
     };
-    float biasv[TN];
+    float biasv[TN], s1[TN], s2[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) biasv[j] = p.bias[n0 + (wn * TN + j) * 16 + LR];   // bias has npad entries
+    for (int j = 0; j < TN; ++j) {
+        biasv[j] = p.bias[n0 + (wn * TN + j) * 16 + LR];   // bias has npad entries
+        s1[j] = 0.f;
+        s2[j] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TH; ++i) {
         unsigned mrow[4];
@@ -205,8 +251,22 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[i][j][r] + bias;
                     if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-                    bstore(v * p.scale, ro0, (nok & mok[r]) ? (mrow[r] * p.ldo0 + n) * 4u : RAFT_OOB);
+                    v *= p.scale;
+                    if (STATS && mok[r]) {
+                        s1[j] += v;
+                        s2[j] = fmaf(v, v, s2[j]);
+                    }
+                    bstore(v, ro0, (nok & mok[r]) ? (mrow[r] * p.ldo0 + n) * 4u : RAFT_OOB);
                 }
+            } else if (EPI == EPI_RES) {
+                float xv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xv[r] = bload(re0, (nok & mok[r]) ? (mrow[r] * p.lde0 + n) * 4u : RAFT_OOB);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    bstore(fmaxf(xv[r] + fmaxf(acc[i][j][r] + bias, 0.f), 0.f), ro0,
+                           (nok & mok[r]) ? (mrow[r] * p.ldo0 + n) * 4u : RAFT_OOB);
             } else if (EPI == EPI_GRU_ZR) {
                 const bool isz = n < p.hid;
                 const unsigned nh = (unsigned)(isz ? n : n - p.hid);
@@ -236,6 +296,19 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
                            (nok & mok[r]) ? (mrow[r] * p.ldo0 + n) * 4u : RAFT_OOB);
                 }
             }
+        }
+    }
+    if (STATS) {
+        // per-tile moments of the raw output: lanes LR, LR+16, LR+32, LR+48 hold the same channel
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float a = s1[j], q = s2[j];
+            a += __shfl_xor(a, 16, 64);
+            q += __shfl_xor(q, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            const int n = n0 + (wn * TN + j) * 16 + LR;
+            if (G == 0) *(float2 *)(p.stats + ((long)mt * p.npad + n) * 2) = make_float2(a, q);
         }
     }
 }

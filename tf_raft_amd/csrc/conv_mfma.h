@@ -42,7 +42,8 @@ enum ConvEpilogue {
     EPI_RELU = 1,     // out = relu(acc + bias) * scale
     EPI_GRU_ZR = 2,   // n <  hid: o0 = sigmoid(v)            (z)
                       // n >= hid: o1 = sigmoid(v) * e0[n-hid] (r * h)
-    EPI_GRU_Q = 3     // o0 = (1 - e1) * e0 + e1 * tanh(v)     (h <- (1-z) h + z q), e0 = h, e1 = z
+    EPI_GRU_Q = 3,    // o0 = (1 - e1) * e0 + e1 * tanh(v)     (h <- (1-z) h + z q), e0 = h, e1 = z
+    EPI_RES = 4       // o0 = relu(e0 + relu(acc + bias))     (ResBlock tail, reference extractor.py:41-49)
 };
 
 struct ConvArgs {
@@ -56,6 +57,11 @@ struct ConvArgs {
     int ldo0, ldo1;
     const float *e0, *e1;
     int lde0, lde1;
+    // ---- halo-tiled kernel only (conv_halo.h); zero-initialised = plain stride-1 'same' convolution
+    int Hi, Wi;                            // input height / width (0: same as the output H, W)
+    int pt, pl;                            // zero padding before the first row / column (TF 'SAME')
+    const float *pre_scale, *pre_shift;    // PRE: input is relu(x * scale[b][c] + shift[b][c]) (fused instance norm)
+    float *stats;                          // STATS: per-tile (sum, sum of squares) of the raw output, [tile][npad][2]
 };
 
 __device__ __forceinline__ float raft_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -1,7 +1,10 @@
 """Device mirror of reference ``tf_raft/layers/extractor.py`` (BasicEncoder / SmallEncoder).
 
-Per BASELINE.json's north_star the encoders are the one part of the path that runs on
-PyTorch-ROCm (dense convolutions on MIOpen / MFMA); everything after them is hand-written HIP.
+Inference (``training=False``, the forward-prediction path) runs on the hand-written halo-tiled
+fp32-MFMA convolutions of ``csrc/conv_halo.h`` through ``raft_encoder_f32`` (``csrc/encoder.hip``):
+batch norm folded into the weights, instance norm fused into the consumer convolution.
+``training=True`` (batch statistics, dropout -- training plumbing, not on the prediction path) keeps
+the PyTorch-ROCm implementation below, which BASELINE.json's north star allows for the encoders.
 TensorFlow semantics that differ from PyTorch defaults are written out explicitly:
   * Keras 'same' padding with stride 2 is asymmetric (extra pixel after)   -- SURVEY F8
   * the 1x1 downsample conv is 'valid' with stride s (extractor.py:37)
@@ -11,12 +14,15 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .. import _dev
+from .. import _dev, _ffi, packing
 from .. import weights as weights_mod
+from .._ffi import check
 
 
 def _same_pad(in_size: int, k: int, stride: int):
@@ -69,6 +75,67 @@ class _Encoder:
             else:
                 a = a.to(dev)
             self.t[k[len(p):]] = a
+        self._pack_device(weights, dev)
+
+    def _pack_device(self, weights, dev):
+        """Pack the weights for ``raft_encoder_f32`` (one device blob + the C struct)."""
+        convs, norms, dims = packing.pack_encoder(weights, self.prefix, self.norm_type)
+        chunks, offs, pos = [], {}, 0
+
+        def add(key, arr):
+            nonlocal pos
+            flat = np.ascontiguousarray(arr, dtype=np.float32).ravel()
+            offs[key] = pos
+            chunks.append(flat)
+            pad = (-flat.size) % 4
+            if pad:
+                chunks.append(np.zeros(pad, dtype=np.float32))
+            pos += flat.size + pad
+
+        for field, wp, b, _ in convs:
+            add((field, 'w'), wp)
+            add((field, 'b'), b)
+        for idx, g, b in norms:
+            add((idx, 'g'), g)
+            add((idx, 'be'), b)
+        self._blob = torch.from_numpy(np.concatenate(chunks)).to(dev)
+        base = self._blob.data_ptr()
+        c = _ffi.EncoderWeights()
+        c.c0, c.c1, c.c2, c.c3, c.cout = dims
+        c.norm = {'instance': _ffi.NORM_INSTANCE, 'batch': _ffi.NORM_FOLDED, None: _ffi.NORM_NONE}[self.norm_type]
+        for field, _, _, npad in convs:
+            cw = _ffi.ConvWeights(wp=base + 4 * offs[(field, 'w')], bias=base + 4 * offs[(field, 'b')], npad=npad)
+            if field == 'conv1':
+                c.conv1 = cw
+            elif field == 'conv2':
+                c.conv2 = cw
+            else:
+                c.block[field[1]][field[2]] = cw
+        for idx, _, _ in norms:
+            c.in_gamma[idx] = base + 4 * offs[(idx, 'g')]
+            c.in_beta[idx] = base + 4 * offs[(idx, 'be')]
+        self.c = c
+        self._ws = None
+
+    def forward_device(self, images: torch.Tensor, input_affine: bool = False) -> torch.Tensor:
+        """(n, H, W, 3) device tensor -> (n, ceil(H/8), ceil(W/8), output_dim) through ``raft_encoder_f32``.
+        ``input_affine`` applies the model's ``2 * (image / 255) - 1`` while staging (model.py:70-71)."""
+        n, H, W, ch = images.shape
+        if ch != 3:
+            raise ValueError(f'images must be (n, H, W, 3), got {tuple(images.shape)}')
+        lib = _dev.lib()
+        need = lib.raft_encoder_workspace_floats(C.byref(self.c), n, H, W)
+        if need <= 0:
+            raise ValueError('invalid encoder geometry')
+        if self._ws is None or self._ws.numel() < need or self._ws.device != images.device:
+            self._ws = torch.empty((need,), device=images.device, dtype=torch.float32)
+        ho, wo = H, W
+        for _ in range(3):
+            ho, wo = (ho + 1) // 2, (wo + 1) // 2
+        out = torch.empty((n, ho, wo, self.output_dim), device=images.device, dtype=torch.float32)
+        check(lib.raft_encoder_f32(C.byref(self.c), _dev.ptr(images), n, H, W, 1 if input_affine else 0,
+                                   _dev.ptr(out), _dev.ptr(self._ws), _dev.stream_ptr()), 'encoder')
+        return out
 
     # ---- building blocks ----------------------------------------------------------------------
     def _conv(self, name, x, stride=1, padding='same'):
@@ -102,7 +169,7 @@ class _Encoder:
             x = self._norm(f'{name}/downsample/1', x, training)
         return F.relu(x + fx)
 
-    def __call__(self, inputs, training=False):
+    def __call__(self, inputs, training=False, _raw_images=False):
         """reference extractor.py:113-130 / 158-175.  NHWC in, NHWC out; a list input is
         concatenated along the batch and split again."""
         is_list = isinstance(inputs, (tuple, list))
@@ -110,6 +177,14 @@ class _Encoder:
             x = torch.cat([_dev.to_device(i) for i in inputs], dim=0)
         else:
             x = _dev.to_device(inputs)
+        if not training:
+            y = self.forward_device(x, input_affine=bool(_raw_images))
+            if is_list:
+                half = y.shape[0] // 2
+                return [_dev.wrap(y[:half]), _dev.wrap(y[half:])]
+            return _dev.wrap(y)
+        if _raw_images:
+            x = 2 * (x / 255.0) - 1.0
         x = x.permute(0, 3, 1, 2)            # NHWC storage viewed as NCHW == channels_last
         x = F.relu(self._norm('norm1', self._conv('conv1', x, 2), training))
         for li, s in ((1, 1), (2, 2), (3, 2)):

@@ -136,13 +136,11 @@ class RAFT:
         B, H, W, _ = image1.shape
         if H % 8 or W % 8:
             raise ValueError(f'H and W must be multiples of 8 (got {H}x{W})')   # model.py:35 uses h//8
-        image1 = 2 * (image1 / 255.0) - 1.0                                     # model.py:70-71
-        image2 = 2 * (image2 / 255.0) - 1.0
-
-        fmap1, fmap2 = self.fnet([image1, image2], training=training)          # model.py:74
+        # model.py:70-71 (2 * (image / 255) - 1) is applied by the encoders while they stage the image
+        fmap1, fmap2 = self.fnet([image1, image2], training=training, _raw_images=True)   # model.py:74
         correlation = CorrBlock(fmap1, fmap2, num_levels=self.corr_levels, radius=self.corr_radius,
                                 alternate=self.alternate_corr)                  # model.py:77
-        cnet = self.cnet(image1, training=training)                            # model.py:82
+        cnet = self.cnet(image1, training=training, _raw_images=True)          # model.py:82
 
         h, w = H // 8, W // 8
         st = self._get_state(B, h, w, image1.device)

@@ -111,3 +111,75 @@ def pack_small_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     out.append(('fh2', np.ascontiguousarray(w[f'{p}/flow_head/conv2/kernel'], dtype=np.float32).reshape(9, 128, 2),
                 np.asarray(w[f'{p}/flow_head/conv2/bias'], dtype=np.float32), 2))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# encoders (reference extractor.py:88-175)
+# ------------------------------------------------------------------------------------------------
+BN_EPS = 1e-3   # Keras BatchNormalization default used by the reference (extractor.py:10)
+
+
+def pack_stem(kernel: np.ndarray, bias: np.ndarray):
+    """7x7 stride-2 stem over the 4-channel padded image: K chunk c = kernel row c, k = kx * 4 + ch
+    (kx < 7, ch < 3; the rest zero).  Returns (wp float32[1, 56, npad, 4], bias[npad], npad)."""
+    kernel = np.asarray(kernel, dtype=np.float32)
+    kh, kw, cin, cout = kernel.shape
+    if (kh, kw, cin) != (7, 7, 3):
+        raise ValueError(f'stem kernel must be (7, 7, 3, Cout), got {kernel.shape}')
+    npad = round_up(cout, 64)
+    full = np.zeros((7, 8, 4, npad), dtype=np.float32)          # [ky][kx][ch][n]
+    full[:, :7, :3, :cout] = kernel
+    wp = full.reshape(1, 56, 4, npad).transpose(0, 1, 3, 2)      # [1][kq = ky*8 + kx][n][ch]
+    b = np.zeros((npad,), dtype=np.float32)
+    b[:cout] = np.asarray(bias, dtype=np.float32)
+    return np.ascontiguousarray(wp), b, npad
+
+
+def _fold_bn(kernel, bias, w, name):
+    """Keras BatchNormalization (inference) folded into the preceding convolution:
+    y = (conv + b - mean) * gamma / sqrt(var + eps) + beta."""
+    if f'{name}/moving_mean' not in w:
+        return kernel, bias
+    s = (w[f'{name}/gamma'].astype(np.float64) / np.sqrt(w[f'{name}/moving_variance'].astype(np.float64) + BN_EPS))
+    k = (kernel.astype(np.float64) * s).astype(np.float32)
+    b = ((bias.astype(np.float64) - w[f'{name}/moving_mean'].astype(np.float64)) * s
+         + w[f'{name}/beta'].astype(np.float64)).astype(np.float32)
+    return k, b
+
+
+def pack_encoder(weights: Dict[str, np.ndarray], prefix: str, norm_type):
+    """Returns (convs, norms, dims): convs = [(field, wp, bias, npad)] with field in
+    {'conv1', 'conv2', ('block', i, j)}; norms = [(index, gamma, beta)] for instance norm;
+    dims = (c0, c1, c2, c3, cout).  Batch norm is folded into the convolutions."""
+    w = {k[len(prefix) + 1:]: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(prefix + '/')}
+    convs, norms = [], []
+
+    def conv(field, name, norm_name, stem=False):
+        k, b = w[f'{name}/kernel'], w[f'{name}/bias']
+        if norm_type == 'batch' and norm_name is not None:
+            k, b = _fold_bn(k, b, w, norm_name)
+        wp, bb, npad = pack_stem(k, b) if stem else pack_conv(k, b)
+        convs.append((field, wp, bb, npad))
+
+    def inorm(index, name):
+        if norm_type == 'instance':
+            norms.append((index, w[f'{name}/gamma'], w[f'{name}/beta']))
+
+    conv('conv1', 'conv1', 'norm1', stem=True)
+    inorm(0, 'norm1')
+    dims = [w['conv1/kernel'].shape[3]]
+    for li in (1, 2, 3):
+        for bi in (0, 1):
+            blk = (li - 1) * 2 + bi
+            name = f'layer{li}/{bi}'
+            conv(('block', blk, 0), f'{name}/conv1', f'{name}/norm1')
+            conv(('block', blk, 1), f'{name}/conv2', f'{name}/norm2')
+            inorm(1 + blk * 3, f'{name}/norm1')
+            inorm(2 + blk * 3, f'{name}/norm2')
+            if f'{name}/downsample/0/kernel' in w:
+                conv(('block', blk, 2), f'{name}/downsample/0', f'{name}/downsample/1')
+                inorm(3 + blk * 3, f'{name}/downsample/1')
+        dims.append(w[f'layer{li}/0/conv1/kernel'].shape[3])
+    conv('conv2', 'conv2', None)
+    dims.append(w['conv2/kernel'].shape[3])
+    return convs, norms, tuple(dims)
