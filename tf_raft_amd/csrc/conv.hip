@@ -218,15 +218,14 @@ __global__ void __launch_bounds__(256) conv7x7_c2_kernel(const float *__restrict
 // ------------------------------------------------------------------------------------------------
 // flow_head.conv2: 3x3, Cout = 2, fused with the coordinate update of the loop
 //   delta = conv(x) + b; coords1 += delta; flow = coords1 - coords0    [update.py:14, model.py:97-102]
-// One wavefront per pixel: lanes split the CIN channels (float4 / float2 per lane), per-lane partial
-// dot products for the 2 outputs, then a wave-wide butterfly reduction.
+// One wavefront per 4 consecutive pixels of a row: lanes split the CIN channels (float4 / float2 per
+// lane, weights of the lane's channels in registers), the 3 x 6 input pixels of the four windows are
+// loaded once (18 independent loads in flight), giving 8 per-lane partial sums (4 pixels x 2 outputs).
+// They are reduced across the 64 lanes by a transpose-reduction: three halving steps (xor 32, 16, 8:
+// each lane keeps half of its values and adds the partner's copies of them) leave one value per lane,
+// three butterfly steps finish it -- 10 shuffles instead of 8 x 6.  Lanes 0, 8, ..., 56 then own one
+// (pixel, component) each and apply the coordinate update.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 template <int CIN>
 __global__ void __launch_bounds__(256) flowhead2_kernel(const float *__restrict__ x, int ldx,
                                                         const float *__restrict__ wk,   // [9][CIN][2]
@@ -237,7 +236,11 @@ __global__ void __launch_bounds__(256) flowhead2_kernel(const float *__restrict_
     constexpr int V = CIN / 64;   // channels per lane (4 or 2)
     static_assert(V == 4 || V == 2, "flowhead2: CIN must be 256 or 128");
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t M = (int64_t)B * H * W;
+    const int ngx = (W + 3) / 4;
+    const int64_t g = (int64_t)blockIdx.x * 4 + wid;          // group of 4 pixels
+    if (g >= (int64_t)B * H * ngx) return;                     // wave-uniform
+    const int gx = (int)(g % ngx), py = (int)((g / ngx) % H), b = (int)(g / ((int64_t)ngx * H));
+    const int x0 = gx * 4;
     // per-lane weights: 9 taps x V channels x 2 outputs
     float w0[9][V], w1[9][V];
 #pragma unroll
@@ -247,45 +250,77 @@ __global__ void __launch_bounds__(256) flowhead2_kernel(const float *__restrict_
             w0[t][v] = wk[((int64_t)t * CIN + lane * V + v) * 2];
             w1[t][v] = wk[((int64_t)t * CIN + lane * V + v) * 2 + 1];
         }
-    const float b0 = bias[0], b1 = bias[1];
-    constexpr int PPW = 8;   // pixels per wave
-    const int64_t mbase = ((int64_t)blockIdx.x * 4 + wid) * PPW;
-    for (int i = 0; i < PPW; ++i) {
-        const int64_t m = mbase + i;
-        if (m >= M) break;
-        const int px = (int)(m % W), py = (int)((m / W) % H);
-        float s0 = 0.f, s1 = 0.f;
+    // the 3 x 6 input pixels (zero outside the image; the conditions are wave-uniform)
+    float in[3][6][V];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;   // wave-uniform
-            const float *src = x + (m + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * ldx + lane * V;
-            float xv[V];
-            if (V == 4) {
-                const f32x4 q = *(const f32x4 *)src;
-                xv[0] = q[0]; xv[1] = q[1]; xv[2] = q[2]; xv[3] = q[3];
-            } else {
-                const float2 q = *(const float2 *)src;
-                xv[0] = q.x; xv[1] = q.y;
-            }
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                s0 = fmaf(xv[v], w0[t][v], s0);
-                s1 = fmaf(xv[v], w1[t][v], s1);
+        for (int c = 0; c < 6; ++c) {
+            const int yy = py + r - 1, xx = x0 + c - 1;
+#pragma unroll
+            for (int v = 0; v < V; ++v) in[r][c][v] = 0.f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const float *src = x + (((int64_t)b * H + yy) * W + xx) * ldx + lane * V;
+                if (V == 4) {
+                    const f32x4 q = *(const f32x4 *)src;
+                    in[r][c][0] = q[0]; in[r][c][1] = q[1]; in[r][c][2] = q[2]; in[r][c][3] = q[3];
+                } else {
+                    const float2 q = *(const float2 *)src;
+                    in[r][c][0] = q.x; in[r][c][1] = q.y;
+                }
             }
         }
-        s0 = wave_sum(s0);
-        s1 = wave_sum(s1);
-        if (lane == 0) {
-            const float dx = s0 + b0, dy = s1 + b1;
-            float2 c = ((float2 *)coords1)[m];
-            c.x += dx;
-            c.y += dy;
-            ((float2 *)coords1)[m] = c;
-            ((float2 *)delta)[m] = make_float2(dx, dy);
-            const float2 f = make_float2(c.x - (float)px, c.y - (float)py);   // coords0 = (x, y) grid
-            ((float2 *)flow)[m] = f;
-            if (flow2) *(float2 *)(flow2 + m * ldf2) = f;
+    float acc[8];   // index = pixel * 2 + component
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float xv = in[t / 3][p + t % 3][v];
+                acc[2 * p] = fmaf(xv, w0[t][v], acc[2 * p]);
+                acc[2 * p + 1] = fmaf(xv, w1[t][v], acc[2 * p + 1]);
+            }
+    // transpose-reduction over the 64 lanes
+    float a4[4], a2[2], a1;
+    {
+        const bool hi = lane & 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float keep = hi ? acc[4 + i] : acc[i], send = hi ? acc[i] : acc[4 + i];
+            a4[i] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool hi = lane & 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float keep = hi ? a4[2 + i] : a4[i], send = hi ? a4[i] : a4[2 + i];
+            a2[i] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool hi = lane & 8;
+        const float keep = hi ? a2[1] : a2[0], send = hi ? a2[0] : a2[1];
+        a1 = keep + __shfl_xor(send, 8, 64);
+    }
+    a1 += __shfl_xor(a1, 4, 64);
+    a1 += __shfl_xor(a1, 2, 64);
+    a1 += __shfl_xor(a1, 1, 64);
+    if ((lane & 7) == 0) {
+        const int idx = lane >> 3;            // = pixel * 2 + component
+        const int px = x0 + (idx >> 1), comp = idx & 1;
+        if (px < W) {
+            const int64_t m = ((int64_t)b * H + py) * W + px;
+            const float d = a1 + bias[comp];
+            const float c = coords1[2 * m + comp] + d;
+            coords1[2 * m + comp] = c;
+            delta[2 * m + comp] = d;
+            const float f = c - (float)(comp ? py : px);     // coords0 = (x, y) grid
+            flow[2 * m + comp] = f;
+            if (flow2) flow2[m * ldf2 + comp] = f;
         }
     }
 }
@@ -442,7 +477,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         RAFT_MARK();
     }
     {   // delta = flow_head.conv2(.), coords1 += delta, flow = coords1 - coords0
-        flowhead2_kernel<256><<<raft_ceil_div(M, 32), 256, 0, s>>>(fm, 512, wts->fh2.wp, wts->fh2.bias, B, h, w,
+        flowhead2_kernel<256><<<raft_ceil_div((int64_t)B * h * ((w + 3) / 4), 4), 256, 0, s>>>(fm, 512, wts->fh2.wp, wts->fh2.bias, B, h, w,
                                                                    st->delta, st->coords1, st->flow, st->x + 254, XDIM);
         RAFT_TRY(raft_launch_status());
         RAFT_MARK();
@@ -607,7 +642,7 @@ extern "C" int raft_update_small_f32(const raft_small_update_weights *wts, int B
         RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
     }
     {   // delta = flow_head.conv2(.), coords1 += delta, flow = coords1 - coords0
-        flowhead2_kernel<128><<<raft_ceil_div(M, 32), 256, 0, s>>>(fh, 128, wts->fh2.wp, wts->fh2.bias, B, h, w,
+        flowhead2_kernel<128><<<raft_ceil_div((int64_t)B * h * ((w + 3) / 4), 4), 256, 0, s>>>(fh, 128, wts->fh2.wp, wts->fh2.bias, B, h, w,
                                                                    st->delta, st->coords1, st->flow,
                                                                    st->x + S_FLOW_SLOT, S_XLD);
         RAFT_TRY(raft_launch_status());

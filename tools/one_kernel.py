@@ -61,8 +61,7 @@ def main():
         ver = sys.argv[2]
         B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
         reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-        if ver == 'v0':
-            os.environ['RAFT_LOOKUP_V0'] = '1'
+        os.environ['RAFT_LOOKUP_VERSION'] = ver.lstrip('v')
         from tf_raft_amd.layers.corr import CorrBlock
         f1 = rng.normal(size=(B, H, W, 256)).astype(np.float32)
         f2 = rng.normal(size=(B, H, W, 256)).astype(np.float32)
