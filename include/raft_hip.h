@@ -177,6 +177,14 @@ int raft_iterate_basic_f32(const raft_basic_update_weights *wts, const float *py
                            const int64_t *level_offsets, int B, int h, int w, int iters,
                            const raft_state *st, float *flow_up, void *stream);
 
+/* The same loop scheduled on three streams: the flow branch (convf1, convf2) and the mask branch (mask2,
+ * convex upsample) run on the caller-owned side streams aux0 / aux1 next to the main chain on `stream`,
+ * ordered by events; everything is joined back into `stream` before the call returns (it still only
+ * enqueues).  Results are identical to raft_iterate_basic_f32. */
+int raft_iterate_basic_overlap_f32(const raft_basic_update_weights *wts, const float *pyr,
+                                   const int64_t *level_offsets, int B, int h, int w, int iters,
+                                   const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1);
+
 /* Profiling twin of raft_iterate_basic_f32 (bench.py only): the same launches with a HIP event
  * recorded on `stream` after every kernel; synchronises the stream and accumulates the elapsed
  * milliseconds of each stage over all iterations into the HOST array stage_ms.  Stage order:

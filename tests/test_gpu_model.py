@@ -260,3 +260,18 @@ def test_alternate_corr_model_matches_volume_model():
     errs = [_max_epe(_np(x), _np(y)) for x, y in zip(a, b)]
     report('alternate corr', worst_epe=max(errs))
     assert max(errs) <= TOL
+
+
+def test_three_stream_loop_is_bitwise_the_single_stream_loop():
+    """raft_iterate_basic_overlap_f32 (flow / mask branches on side streams) must reproduce
+    raft_iterate_basic_f32 bit for bit on every prediction, repeatedly (no races)."""
+    import tf_raft_amd
+    from tf_raft_amd import weights as wm
+    wts = wm.init_weights('raft', seed=2)
+    i1, i2 = _images(4, 2, 128, 192)
+    ref = [_np(p) for p in tf_raft_amd.RAFT(weights=wts, iters_pred=8, overlap=False)([i1, i2])]
+    model = tf_raft_amd.RAFT(weights=wts, iters_pred=8, overlap=True)
+    for _ in range(3):
+        got = [_np(p) for p in model([i1, i2])]
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b)

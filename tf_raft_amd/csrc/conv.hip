@@ -415,12 +415,31 @@ struct StageTimer {
         if (tm) tm->mark(s);        \
     } while (0)
 
+// Optional three-stream schedule of one loop iteration (raft_iterate_basic_overlap_f32):
+//   main  lookup, convc1, convc2, [join flow branch] conv, GRU, [join previous upsample] fh1_mask0, fh2
+//   s1    convf1, convf2                 (needs only the previous iteration's flow)
+//   s2    mask2, upsample                (feed nothing inside the loop; must drain before the next fh1_mask0
+//                                         overwrites their inputs)
+// so the small / short / one-workgroup-per-CU kernels run in the shadows of the big ones.
+struct Overlap {
+    hipStream_t s1, s2;
+    hipEvent_t e_fh, e_f, e_fm, e_up;   // after fh2, after convf2, after fh1_mask0, after upsample
+    bool have_up;                       // e_up has been recorded (false in the first iteration)
+};
+#define RAFT_HIP(expr)                       \
+    do {                                     \
+        hipError_t e__ = (expr);             \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
 static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h, int w, const raft_state *st,
-                             void *stream, StageTimer *tm) {
+                             void *stream, StageTimer *tm, Overlap *ov = nullptr) {
     RAFT_REQUIRE_PTR(wts);
     RAFT_TRY(check_state(st));
     RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
     hipStream_t s = (hipStream_t)stream;
+    hipStream_t sf = ov ? ov->s1 : s;   // flow branch
+    hipStream_t sm = ov ? ov->s2 : s;   // mask branch
     const int64_t M = (int64_t)B * h * w;
     float *ws = st->ws;
     float *cor1 = ws + M * WS_COR1, *corflo = ws + M * WS_CORFLO, *flo1 = ws + M * WS_FLO1;
@@ -437,16 +456,21 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
         RAFT_MARK();
     }
+    if (ov) RAFT_HIP(hipStreamWaitEvent(sf, ov->e_fh, 0));   // flow of the previous iteration is final
     {   // flo = relu(convf1(flow))            7x7, 2 -> 128
         const int xt = (w + 31) / 32;
-        conv7x7_c2_kernel<128><<<B * h * xt, 256, 0, s>>>(st->flow, wts->convf1.wp, wts->convf1.bias, B, h, w, flo1, 128);
+        conv7x7_c2_kernel<128><<<B * h * xt, 256, 0, sf>>>(st->flow, wts->convf1.wp, wts->convf1.bias, B, h, w, flo1, 128);
         RAFT_TRY(raft_launch_status());
         RAFT_MARK();
     }
     {   // flo = relu(convf2(flo))             3x3, 128 -> 64    -> corflo[:, 192:256]
         ConvArgs a = conv_args(wts->convf2, flo1, 128, 128, nullptr, 0, 0, B, h, w, 64, corflo + 192, 256);
-        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, sf));
         RAFT_MARK();
+    }
+    if (ov) {
+        RAFT_HIP(hipEventRecord(ov->e_f, sf));
+        RAFT_HIP(hipStreamWaitEvent(s, ov->e_f, 0));
     }
     {   // out = relu(conv(cat[cor, flo]))     3x3, 256 -> 126   -> x[:, 128:254]; x[:, 254:256] = flow (kept by flowhead2)
         ConvArgs a = conv_args(wts->conv, corflo, 256, 256, nullptr, 0, 0, B, h, w, 126, st->x + 128, XDIM);
@@ -471,10 +495,15 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
             RAFT_MARK();
         }
     }
+    if (ov && ov->have_up) RAFT_HIP(hipStreamWaitEvent(s, ov->e_up, 0));   // mask2 / upsample of the previous iteration
     {   // relu(flow_head.conv1(net)) | relu(mask.0(net))   3x3, 128 -> 256 + 256
         ConvArgs a = conv_args(wts->fh1_mask0, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 512, fm, 512);
         RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
         RAFT_MARK();
+    }
+    if (ov) {
+        RAFT_HIP(hipEventRecord(ov->e_fm, s));
+        RAFT_HIP(hipStreamWaitEvent(sm, ov->e_fm, 0));
     }
     {   // delta = flow_head.conv2(.), coords1 += delta, flow = coords1 - coords0
         flowhead2_kernel<256><<<raft_ceil_div((int64_t)B * h * ((w + 3) / 4), 4), 256, 0, s>>>(fm, 512, wts->fh2.wp, wts->fh2.bias, B, h, w,
@@ -482,10 +511,11 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         RAFT_TRY(raft_launch_status());
         RAFT_MARK();
     }
+    if (ov) RAFT_HIP(hipEventRecord(ov->e_fh, s));
     {   // mask = 0.25 * mask.2(.)             1x1, 256 -> 576
         ConvArgs a = conv_args(wts->mask2, fm + 256, 512, 256, nullptr, 0, 0, B, h, w, 576, st->mask, 576);
         a.scale = 0.25f;
-        RAFT_TRY(raft_launch_conv(a, 1, 1, EPI_LINEAR, s));
+        RAFT_TRY(raft_launch_conv(a, 1, 1, EPI_LINEAR, sm));
         RAFT_MARK();
     }
     return RAFT_OK;
@@ -512,6 +542,50 @@ extern "C" int raft_iterate_basic_f32(const raft_basic_update_weights *wts, cons
         RAFT_TRY(raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream));
     }
     return RAFT_OK;
+}
+
+// raft_iterate_basic_f32 on three streams (see struct Overlap).  aux0 / aux1 are caller-owned streams
+// distinct from `stream`; all work is joined back into `stream` before returning.
+extern "C" int raft_iterate_basic_overlap_f32(const raft_basic_update_weights *wts, const float *pyr,
+                                              const int64_t *level_offsets, int B, int h, int w, int iters,
+                                              const raft_state *st, float *flow_up, void *stream, void *aux0,
+                                              void *aux1) {
+    RAFT_REQUIRE_PTR(wts);
+    RAFT_REQUIRE_PTR(pyr);
+    RAFT_REQUIRE_PTR(level_offsets);
+    RAFT_REQUIRE_PTR(flow_up);
+    RAFT_REQUIRE_PTR(aux0);
+    RAFT_REQUIRE_PTR(aux1);
+    RAFT_TRY(check_state(st));
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0 && iters > 0, RAFT_E_SHAPE);
+    RAFT_REQUIRE(aux0 != stream && aux1 != stream && aux0 != aux1, RAFT_E_UNSUPPORTED);
+    hipStream_t s = (hipStream_t)stream;
+    Overlap ov = {};
+    ov.s1 = (hipStream_t)aux0;
+    ov.s2 = (hipStream_t)aux1;
+    hipEvent_t *evs[4] = {&ov.e_fh, &ov.e_f, &ov.e_fm, &ov.e_up};
+    int rc = RAFT_OK;
+    int made = 0;
+    for (; made < 4 && rc == RAFT_OK; ++made) rc = (int)hipEventCreateWithFlags(evs[made], hipEventDisableTiming);
+    if (rc != RAFT_OK) --made;
+    const int64_t up = (int64_t)B * 64 * h * w * 2;
+    if (rc == RAFT_OK) rc = (int)hipEventRecord(ov.e_fh, s);   // state prepared on `stream`: the flow branch may start
+    for (int i = 0; i < iters && rc == RAFT_OK; ++i) {
+        rc = raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream);
+        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov);
+        // upsample on the mask branch: needs mask2 (same stream) and the flow written by fh2
+        if (rc == RAFT_OK) rc = (int)hipStreamWaitEvent(ov.s2, ov.e_fh, 0);
+        if (rc == RAFT_OK) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, ov.s2);
+        if (rc == RAFT_OK) rc = (int)hipEventRecord(ov.e_up, ov.s2);
+        ov.have_up = true;
+    }
+    if (rc == RAFT_OK && ov.have_up) rc = (int)hipStreamWaitEvent(s, ov.e_up, 0);   // join
+    if (rc != RAFT_OK) {   // never leave side streams running behind an error return
+        (void)hipStreamSynchronize(ov.s1);
+        (void)hipStreamSynchronize(ov.s2);
+    }
+    for (int k = 0; k < made; ++k) (void)hipEventDestroy(*evs[k]);
+    return rc;
 }
 
 // Profiling twin of raft_iterate_basic_f32: identical launches, plus a HIP event after every kernel

@@ -20,6 +20,7 @@ Out of scope (training plumbing of the reference, model.py:111-170): ``compile``
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -39,7 +40,7 @@ class RAFT:
     variant = 'raft'
 
     def __init__(self, drop_rate=0, iters=12, iters_pred=24, weights: Optional[Dict[str, np.ndarray]] = None,
-                 seed=0, alternate_corr=False, **kwargs):
+                 seed=0, alternate_corr=False, overlap=None, **kwargs):
         if kwargs:
             raise TypeError(f'unexpected keyword arguments {sorted(kwargs)}')
         self.hidden_dim = 128
@@ -50,6 +51,9 @@ class RAFT:
         self.iters = iters
         self.iters_pred = iters_pred
         self.alternate_corr = alternate_corr
+        # three-stream schedule of the loop (RAFT only); RAFT_OVERLAP=0 forces the single-stream loop
+        self.overlap = (os.environ.get('RAFT_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
+        self._aux = None
         self._state = None
         _dev.require_gpu()
         _dev.lib()
@@ -108,6 +112,16 @@ class RAFT:
                                                 _dev.stream_ptr()), 'prepare_state')
 
     def _iterate(self, corr: CorrBlock, st, iters, flow_up):
+        if self.overlap:
+            # flow branch and mask branch of every iteration on two side streams (events inside the library)
+            dev = flow_up.device
+            if self._aux is None or self._aux[0].device != dev:
+                self._aux = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            check(_dev.lib().raft_iterate_basic_overlap_f32(
+                C.byref(self.update_block.c), _dev.ptr(corr._pyr), corr._off, st.B, st.h, st.w, iters, C.byref(st.c),
+                _dev.ptr(flow_up), _dev.stream_ptr(), self._aux[0].cuda_stream, self._aux[1].cuda_stream),
+                'iterate_basic_overlap')
+            return
         check(_dev.lib().raft_iterate_basic_f32(C.byref(self.update_block.c), _dev.ptr(corr._pyr), corr._off,
                                                 st.B, st.h, st.w, iters, C.byref(st.c), _dev.ptr(flow_up),
                                                 _dev.stream_ptr()), 'iterate_basic')
