@@ -119,6 +119,66 @@ def test_pack_update_blocks_cover_every_struct_field():
     assert szr[0].shape == (9, 64, 192, 4)                           # K = 96 + 160 (146 padded)
 
 
+def test_pack_stem_layout_reproduces_the_stride2_convolution(rng):
+    """The 7x7/2 stem is packed as 7 K-chunks (one per kernel row) of k = kx*4 + ch over the 4-channel
+    padded image; evaluate it exactly the way csrc/conv_halo.h (STEM mode) indexes it."""
+    from oracle import tf_ops
+    cout, H, W = 6, 12, 10
+    kernel = rng.normal(size=(7, 7, 3, cout)).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    wp, b, npad = packing.pack_stem(kernel, bias)
+    assert wp.shape == (1, 56, 64, 4) and npad == 64
+    img = rng.normal(size=(1, H, W, 3)).astype(np.float32)
+    img4 = np.zeros((1, H, W, 4), np.float64)
+    img4[..., :3] = img
+    (pt, _), (pl, _) = tf_ops.same_padding(H, 7, 2), tf_ops.same_padding(W, 7, 2)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    got = np.zeros((1, Ho, Wo, cout))
+    for y in range(Ho):
+        for x in range(Wo):
+            for c in range(7):                       # K chunk = kernel row
+                yy = 2 * y - pt + c
+                for c4 in range(8):                  # 16-byte quad = kernel column (7 used)
+                    xx = 2 * x - pl + c4
+                    if c4 < 7 and 0 <= yy < H and 0 <= xx < W:
+                        got[0, y, x] += img4[0, yy, xx] @ wp[0, c * 8 + c4, :cout, :].T.astype(np.float64)
+    got += b[:cout]
+    want = tf_ops.conv2d(torch.as_tensor(img).double(), torch.as_tensor(kernel).double(),
+                         torch.as_tensor(bias).double(), stride=2).numpy()
+    np.testing.assert_allclose(got, want, atol=1e-5)
+    assert not wp[0, 7::8].any() and not wp[..., 3].any()             # zero padding column / channel
+
+
+def test_pack_encoder_folds_batch_norm_and_covers_every_layer(rng):
+    from oracle import tf_ops
+    wts = wm.init_weights('raft', seed=1, perturb=True)
+    convs, norms, dims = packing.pack_encoder(wts, 'cnet', 'batch')
+    assert dims == (64, 64, 96, 128, 256) and norms == []
+    fields = [f for f, *_ in convs]
+    assert fields[0] == 'conv1' and fields[-1] == 'conv2' and len(fields) == 1 + 6 * 2 + 2 + 1
+    assert ('block', 2, 2) in fields and ('block', 4, 2) in fields and ('block', 0, 2) not in fields
+    # folded conv == conv followed by inference batch norm
+    name = 'cnet/layer2/0/conv2'
+    k, bias = wts[f'{name}/kernel'], wts[f'{name}/bias']
+    n = 'cnet/layer2/0/norm2'
+    kf, bf = packing._fold_bn(k, bias, {kk[len('cnet/'):]: v for kk, v in wts.items() if kk.startswith('cnet/')},
+                              'layer2/0/norm2')
+    x = torch.as_tensor(rng.normal(size=(1, 5, 6, k.shape[2]))).double()
+    want = tf_ops.batch_norm(tf_ops.conv2d(x, torch.as_tensor(k).double(), torch.as_tensor(bias).double()),
+                             *[torch.as_tensor(wts[f'{n}/{q}']).double() for q in ('gamma', 'beta', 'moving_mean',
+                                                                                 'moving_variance')])
+    got = tf_ops.conv2d(x, torch.as_tensor(kf).double(), torch.as_tensor(bf).double())
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=1e-5)
+    # instance norm: affine parameters are passed through, indexed stem = 0, block i -> 1 + 3 i + {0, 1, 2}
+    convs, norms, dims = packing.pack_encoder(wts, 'fnet', 'instance')
+    idx = sorted(i for i, _, _ in norms)
+    assert idx == sorted([0] + [1 + 3 * b + j for b in range(6) for j in (0, 1)] + [1 + 3 * 2 + 2, 1 + 3 * 4 + 2])
+    small = packing.pack_encoder(wm.init_weights('small', seed=1), 'cnet', None)
+    assert small[2] == (32, 32, 64, 96, 160) and small[1] == []
+    enc = _ffi.EncoderWeights()
+    assert len(enc.in_gamma) == 19 and len(enc.block) == 6 and len(enc.block[0]) == 3
+
+
 # ---------------------------------------------------------------- C ABI
 def _declared_functions():
     with open(os.path.join(ROOT, 'include', 'raft_hip.h')) as f:
