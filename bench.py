@@ -44,8 +44,10 @@ def stage_work(B, h, w):
     M = B * h * w
     macs = {
         'convc1': 324 * 256, 'convc2': 9 * 256 * 192, 'convf1': 49 * 2 * 128, 'convf2': 9 * 128 * 64,
-        'conv': 9 * 256 * 126, 'gru_zr1': 5 * 384 * 256, 'gru_q1': 5 * 384 * 128, 'gru_zr2': 5 * 384 * 256,
-        'gru_q2': 5 * 384 * 128, 'fh1_mask0': 9 * 128 * 512, 'fh2': 9 * 256 * 2, 'mask2': 256 * 576,
+        # SepConvGRU rows of `inp` (128 of the 384 input channels) are loop-invariant and evaluated once per
+        # forward by raft_gru_context_f32 (pre-loop 'gru_context': 2 x 5*128*384 MAC/px): executed K = 5*256
+        'conv': 9 * 256 * 126, 'gru_zr1': 5 * 256 * 256, 'gru_q1': 5 * 256 * 128, 'gru_zr2': 5 * 256 * 256,
+        'gru_q2': 5 * 256 * 128, 'fh1_mask0': 9 * 128 * 512, 'fh2': 9 * 256 * 2, 'mask2': 256 * 576,
     }
     flops = {k: 2.0 * v * M for k, v in macs.items()}
     bytes_ = {
@@ -150,7 +152,7 @@ def main():
         ev[4].record()
         torch.cuda.synchronize()
         pre_ms = {'fnet': ev[0].elapsed_time(ev[1]), 'cnet': ev[1].elapsed_time(ev[2]),
-                  'corr_build': ev[2].elapsed_time(ev[3]), 'prepare_state': ev[3].elapsed_time(ev[4])}
+                  'corr_build': ev[2].elapsed_time(ev[3]), 'prepare_state+gru_context': ev[3].elapsed_time(ev[4])}
         flow_up = torch.empty((ITERS, B, H, W, 2), device=device)
         acc = np.zeros(len(STAGES), dtype=np.float64)
         buf = (C.c_float * len(STAGES))()

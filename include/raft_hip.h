@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 100          /* 0.1.0 */
+#define RAFT_HIP_VERSION 101          /* 0.1.1 */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -139,11 +139,17 @@ typedef struct raft_conv_weights {
  * half are fused along N (npad 256 = [z | r]); flow_head.conv1 and mask[0] are fused along N
  * (npad 512 = [flow_head.conv1 | mask.0]).
  * convf1: (7,7,2,128) kept in Keras layout [t][c][n] (98 x 128 floats).
- * fh2: flow_head.conv2 (3,3,256,2) kept in Keras layout [t][c][2]. */
+ * fh2: flow_head.conv2 (3,3,256,2) kept in Keras layout [t][c][2].
+ * SepConvGRU (update.py:38-67), input order hx = [h(128) | inp(128) | motion(126) | flow(2)]: the rows of
+ * convz / convr / convq that multiply `inp` are split off into gru_ctx1 (1x5) / gru_ctx2 (5x1), each
+ * (kh,kw,128,384) = [z | r | q] WITH the three biases; gru_zr{1,2} / gru_q{1,2} keep the h rows and the
+ * [motion | flow] rows (K = 256 per tap) and carry ZERO bias.  `inp` is constant over the prediction
+ * loop, so its contribution is evaluated once per forward (raft_gru_context_f32). */
 typedef struct raft_basic_update_weights {
     raft_conv_weights convc1, convc2, convf1, convf2, conv;
     raft_conv_weights gru_zr1, gru_q1, gru_zr2, gru_q2;
     raft_conv_weights fh1_mask0, fh2, mask2;
+    raft_conv_weights gru_ctx1, gru_ctx2;
 } raft_basic_update_weights;
 
 /* Device state of the recurrent loop (all caller-owned, (B*h*w) pixels, NHWC):
@@ -152,9 +158,11 @@ typedef struct raft_basic_update_weights {
  *                   raft_prepare_state_f32, the rest every iteration
  *   corr   (M,352)  lookup output, 324 used + 28 zero pad channels
  *   coords1(M,2), flow (M,2), delta (M,2), mask (M,576)
- *   ws              scratch, raft_update_workspace_floats() floats */
+ *   ws              scratch, raft_update_workspace_floats() floats
+ *   ctx    (M,768)  loop-invariant GRU pre-activation terms [z1 | r1 | q1 | z2 | r2 | q2] of `inp`,
+ *                   written by raft_gru_context_f32 (BasicUpdateBlock only; SmallRAFT ignores it) */
 typedef struct raft_state {
-    float *net, *x, *corr, *coords1, *flow, *delta, *mask, *ws;
+    float *net, *x, *corr, *coords1, *flow, *delta, *mask, *ws, *ctx;
 } raft_state;
 
 int64_t raft_update_workspace_floats(int B, int h, int w);
@@ -164,8 +172,15 @@ int64_t raft_update_workspace_floats(int B, int h, int w);
 int raft_prepare_state_f32(const float *cnet, int B, int h, int w, const raft_state *st,
                            void *stream);
 
+/* conv{z,r,q}{1,2} restricted to the `inp` rows of the GRU input, plus their biases -> st->ctx.
+ * Must run after raft_prepare_state_f32 (or any other write of x[:, 0:128]) and before
+ * raft_update_basic_f32 / raft_iterate_basic_*; reference update.py:51-67 evaluates these rows inside
+ * every SepConvGRU call, model.py:86 shows `inp` is fixed for the whole loop. */
+int raft_gru_context_f32(const raft_basic_update_weights *wts, int B, int h, int w,
+                         const raft_state *st, void *stream);
+
 /* One BasicUpdateBlock call + the coordinate update (reference update.py:143-153 and
- * model.py:97-102): reads st->corr, st->flow, st->net, st->x; writes st->net, st->mask
+ * model.py:97-102): reads st->corr, st->flow, st->net, st->x, st->ctx; writes st->net, st->mask
  * (already scaled by 0.25), st->delta, st->coords1 (+= delta), st->flow (coords1 - coords0). */
 int raft_update_basic_f32(const raft_basic_update_weights *wts, int B, int h, int w,
                           const raft_state *st, void *stream);

@@ -112,11 +112,42 @@ def test_pack_update_blocks_cover_every_struct_field():
     basic = packing.pack_basic_update({k: v for k, v in wm.init_weights('raft', 0).items()})
     assert [f for f, *_ in basic] == [n for n, _ in _ffi.BasicUpdateWeights._fields_]
     zr = dict((f, (wp, b, n)) for f, wp, b, n in basic)['gru_zr1']
-    assert zr[0].shape == (5, 96, 256, 4) and zr[2] == 256           # [z | r] fused along N
+    assert zr[0].shape == (5, 64, 256, 4) and zr[2] == 256           # [z | r] fused along N; K = h + [motion | flow]
+    assert not zr[1].any()                                           # the biases ride in the context convolution
+    ctx = dict((f, (wp, b, n)) for f, wp, b, n in basic)['gru_ctx1']
+    assert ctx[0].shape == (5, 32, 384, 4) and ctx[2] == 384         # inp rows -> [z | r | q]
     small = packing.pack_small_update(wm.init_weights('small', 0))
     assert [f for f, *_ in small] == [n for n, _ in _ffi.SmallUpdateWeights._fields_]
     szr = dict((f, (wp, b, n)) for f, wp, b, n in small)['gru_zr']
     assert szr[0].shape == (9, 64, 192, 4)                           # K = 96 + 160 (146 padded)
+
+
+@pytest.mark.parametrize('s,ksize', [('1', (1, 5)), ('2', (5, 1))])
+def test_gru_context_split_reproduces_the_full_convolution(rng, s, ksize):
+    """convz/convr/convq over hx = [h | inp | motion | flow] (reference update.py:53-65) ==
+    context convolution over inp (with the biases) + loop convolution over [h | motion | flow] (zero bias),
+    evaluated from the packed arrays exactly as the kernels index them."""
+    from oracle import tf_ops
+    wts = wm.init_weights('raft', 3)
+    for k in list(wts):
+        if k.endswith('/bias'):
+            wts[k] = rng.normal(size=wts[k].shape).astype(np.float32)
+    packed = dict((f, (wp, b, n)) for f, wp, b, n in packing.pack_basic_update(wts))
+    kh, kw = ksize
+    hx = rng.normal(size=(1, 6, 7, 384)).astype(np.float32)
+    p = 'update_block/gru'
+    for field, names, nout in ((f'gru_zr{s}', [f'convz{s}', f'convr{s}'], 256), (f'gru_q{s}', [f'convq{s}'], 128)):
+        kern = np.concatenate([wts[f'{p}/{n}/kernel'] for n in names], 3)
+        bias = np.concatenate([wts[f'{p}/{n}/bias'] for n in names])
+        want = tf_ops.conv2d(torch.as_tensor(hx).double(), torch.as_tensor(kern).double(),
+                             torch.as_tensor(bias).double()).numpy()
+        wp, b, npad = packed[field]
+        loop_in = np.concatenate([hx[..., :128], hx[..., 256:]], -1)
+        loop = _unpacked_conv(loop_in, wp, b, kh, kw, None, nout)
+        cwp, cb, cn = packed[f'gru_ctx{s}']
+        ctx = _unpacked_conv(hx[..., 128:256], cwp, cb, kh, kw, None, 384)
+        ctx = ctx[..., :256] if nout == 256 else ctx[..., 256:384]
+        np.testing.assert_allclose(loop + ctx, want, atol=1e-4)
 
 
 def test_pack_stem_layout_reproduces_the_stride2_convolution(rng):
@@ -196,7 +227,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in include/raft_hip.h but not exported'
     assert sorted(_ffi.EXPORTED_SYMBOLS) == names, 'ctypes signature table and header disagree'
     typed = _ffi.load_library()
-    assert typed.raft_version() == 100
+    assert typed.raft_version() == 101
     assert b'NULL' in typed.raft_error_string(-1)
     assert typed.raft_error_string(0) == b'ok'
 

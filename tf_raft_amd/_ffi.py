@@ -25,7 +25,7 @@ class BasicUpdateWeights(C.Structure):
     _fields_ = [(n, ConvWeights) for n in (
         'convc1', 'convc2', 'convf1', 'convf2', 'conv',
         'gru_zr1', 'gru_q1', 'gru_zr2', 'gru_q2',
-        'fh1_mask0', 'fh2', 'mask2')]
+        'fh1_mask0', 'fh2', 'mask2', 'gru_ctx1', 'gru_ctx2')]
 
 
 class SmallUpdateWeights(C.Structure):
@@ -44,7 +44,7 @@ NORM_NONE, NORM_INSTANCE, NORM_FOLDED = 0, 1, 2
 
 class State(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        'net', 'x', 'corr', 'coords1', 'flow', 'delta', 'mask', 'ws')]
+        'net', 'x', 'corr', 'coords1', 'flow', 'delta', 'mask', 'ws', 'ctx')]
 
 
 _P = C.c_void_p
@@ -66,6 +66,7 @@ _SIGNATURES = {
                              C.c_float, _P, _I, _P]),
     'raft_update_workspace_floats': (C.c_int64, [_I, _I, _I]),
     'raft_prepare_state_f32': (_I, [_P, _I, _I, _I, C.POINTER(State), _P]),
+    'raft_gru_context_f32': (_I, [C.POINTER(BasicUpdateWeights), _I, _I, _I, C.POINTER(State), _P]),
     'raft_update_basic_f32': (_I, [C.POINTER(BasicUpdateWeights), _I, _I, _I, C.POINTER(State), _P]),
     'raft_iterate_basic_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
                                     C.POINTER(State), _P, _P]),

@@ -82,7 +82,7 @@ static int forced_code(int npad, int taps) {
 // per SIMD exposes prologue / barrier / epilogue latency, three or more hide it.
 static int pick_code(const ConvArgs &a, int kh, int kw) {
     const int f = forced_code(a.npad, kh * kw);
-    if (f >= 0) return f;
+    if (f >= 100 || (f >= 0 && !a.init)) return f;   // the legacy tiles have no accumulator preload
     static const int ths[3] = {4, 7, 8};
     double best = 1e30;
     int best_code = 141;
@@ -132,6 +132,10 @@ int raft_launch_conv(const ConvArgs &a_in, int kh, int kw, int epi, hipStream_t 
     const bool known = (kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 1 && kw == 5) || (kh == 5 && kw == 1);
     if (!known) return RAFT_E_UNSUPPORTED;
     const int code = pick_code(a, kh, kw);
+    if (a.init) {
+        const int64_t M = (int64_t)a.B * a.H * a.W;
+        if (M * a.ldi * 4 >= ((int64_t)1 << 31)) return RAFT_E_UNSUPPORTED;
+    }
     if (code >= 100) {
         const int th = (code - 100) / 10, tn = (code - 100) % 10;
         if (kh == 1 && kw == 1) return raft_launch_conv_halo_1x1(a, th, tn, epi, s);
@@ -362,6 +366,8 @@ __global__ void __launch_bounds__(256) prepare_state_kernel(const float *__restr
 namespace {
 constexpr int WS_COR1 = 0, WS_CORFLO = 256, WS_FLO1 = 512, WS_Z = 640, WS_RH = 768, WS_FM = 896, WS_PER_PIX = 1408;
 constexpr int HDIM = 128, XDIM = 256, CORR_LD = 352, CORR_USED = 324;
+constexpr int CDIM = 128;               // inp channels = x[:, 0:CDIM]; x[:, CDIM:XDIM] = [motion 126 | flow 2]
+constexpr int CTX_LD = 6 * HDIM;        // [z1 | r1 | q1 | z2 | r2 | q2] context terms per pixel
 }   // namespace
 
 extern "C" int64_t raft_update_workspace_floats(int B, int h, int w) {
@@ -379,6 +385,7 @@ static int check_state(const raft_state *st) {
     RAFT_REQUIRE_PTR(st->delta);
     RAFT_REQUIRE_PTR(st->mask);
     RAFT_REQUIRE_PTR(st->ws);
+    RAFT_REQUIRE_PTR(st->ctx);
     return RAFT_OK;
 }
 
@@ -400,6 +407,25 @@ static ConvArgs conv_args(const raft_conv_weights &wt, const float *a0, int lda0
     a.wp = wt.wp; a.bias = wt.bias; a.npad = wt.npad; a.nvalid = nvalid;
     a.B = B; a.H = h; a.W = w; a.scale = 1.0f; a.o0 = o0; a.ldo0 = ldo0;
     return a;
+}
+
+// Loop-invariant part of the SepConvGRU.  hx = [h | inp | motion | flow] and [r*h | inp | motion | flow]
+// (update.py:53, 58, 63): `inp` never changes inside the prediction loop (model.py:86, 91-106), so the
+// inp rows of convz / convr / convq contribute the same pre-activation term in every iteration.  It is
+// computed here once per forward -- one 1x5 and one 5x1 convolution 128 -> [z | r | q] (the biases ride
+// along) -- and the per-iteration GRU convolutions start their accumulators from it and walk only the
+// h / motion / flow rows (K = 5 * 256 instead of 5 * 384).
+extern "C" int raft_gru_context_f32(const raft_basic_update_weights *wts, int B, int h, int w,
+                                    const raft_state *st, void *stream) {
+    RAFT_REQUIRE_PTR(wts);
+    RAFT_TRY(check_state(st));
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
+    for (int pass = 0; pass < 2; ++pass) {
+        const raft_conv_weights &wc = pass == 0 ? wts->gru_ctx1 : wts->gru_ctx2;
+        ConvArgs a = conv_args(wc, st->x, XDIM, CDIM, nullptr, 0, 0, B, h, w, 3 * HDIM, st->ctx + pass * 3 * HDIM, CTX_LD);
+        RAFT_TRY(raft_launch_conv(a, pass == 0 ? 1 : 5, pass == 0 ? 5 : 1, EPI_LINEAR, (hipStream_t)stream));
+    }
+    return RAFT_OK;
 }
 
 // Optional per-stage HIP-event recorder (profiling entry point only; see raft_iterate_basic_timed_f32).
@@ -482,15 +508,19 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         const raft_conv_weights &wzr = pass == 0 ? wts->gru_zr1 : wts->gru_zr2;
         const raft_conv_weights &wq = pass == 0 ? wts->gru_q1 : wts->gru_q2;
         const int kh = pass == 0 ? 1 : 5, kw = pass == 0 ? 5 : 1;
+        const float *xm = st->x + CDIM;                      // [motion | flow]; the inp rows live in st->ctx
+        const float *ctx = st->ctx + pass * 3 * HDIM;        // [z | r | q] context of this pass
         {
-            ConvArgs a = conv_args(wzr, st->net, HDIM, HDIM, st->x, XDIM, XDIM, B, h, w, 2 * HDIM, zb, HDIM);
+            ConvArgs a = conv_args(wzr, st->net, HDIM, HDIM, xm, XDIM, XDIM - CDIM, B, h, w, 2 * HDIM, zb, HDIM);
             a.hid = HDIM; a.o1 = rh; a.ldo1 = HDIM; a.e0 = st->net; a.lde0 = HDIM;
+            a.init = ctx; a.ldi = CTX_LD;
             RAFT_TRY(raft_launch_conv(a, kh, kw, EPI_GRU_ZR, s));
             RAFT_MARK();
         }
         {
-            ConvArgs a = conv_args(wq, rh, HDIM, HDIM, st->x, XDIM, XDIM, B, h, w, HDIM, st->net, HDIM);
+            ConvArgs a = conv_args(wq, rh, HDIM, HDIM, xm, XDIM, XDIM - CDIM, B, h, w, HDIM, st->net, HDIM);
             a.e0 = st->net; a.lde0 = HDIM; a.e1 = zb; a.lde1 = HDIM;
+            a.init = ctx + 2 * HDIM; a.ldi = CTX_LD;
             RAFT_TRY(raft_launch_conv(a, kh, kw, EPI_GRU_Q, s));
             RAFT_MARK();
         }

@@ -169,6 +169,26 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
 
     gload(0);
     frag_b(0, 0, fb[0]);
+    if (p.init) {
+        // accumulators start from a precomputed partial sum (lane owns channel n; register r of
+        // accumulator (i, j) is pixel (y0 + i, x0 + 4G + r)); issued behind the first tile's loads
+        const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)p.init, 0, (int)((((long)M - 1) * p.ldi + p.nvalid) * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TH; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 16 + LR;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int yy = y0 + i, xx = x0 + 4 * G + r;
+                    const bool ok = (yy < p.H) & (xx < p.W) & (n < p.nvalid);
+                    const unsigned m = (unsigned)((b * p.H + yy) * p.W + xx);
+                    acc[i][j][r] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(ri, ok ? (int)((m * p.ldi + n) * 4u) : (int)RAFT_OOB, 0, 0));
+                }
+            }
+    }
     lstore(0);
     __syncthreads();
     if (nch > 1) gload(1);

@@ -62,6 +62,8 @@ struct ConvArgs {
     int pt, pl;                            // zero padding before the first row / column (TF 'SAME')
     const float *pre_scale, *pre_shift;    // PRE: input is relu(x * scale[b][c] + shift[b][c]) (fused instance norm)
     float *stats;                          // STATS: per-tile (sum, sum of squares) of the raw output, [tile][npad][2]
+    const float *init;                     // accumulators start from init[pixel * ldi + n] instead of 0 (NULL: 0):
+    int ldi;                               //   a precomputed partial convolution (loop-invariant GRU context term)
 };
 
 __device__ __forceinline__ float raft_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -21,8 +21,8 @@ from .._ffi import check
 
 _GEOM = {
     # variant: hdim, cdim, x_ld, flow_slot, corr_ld, corr_used, radius, mask
-    'raft': dict(hdim=128, cdim=128, x_ld=256, flow_slot=254, corr_ld=352, corr_used=324, radius=4, mask=576),
-    'small': dict(hdim=96, cdim=64, x_ld=160, flow_slot=144, corr_ld=224, corr_used=196, radius=3, mask=0),
+    'raft': dict(hdim=128, cdim=128, x_ld=256, flow_slot=254, corr_ld=352, corr_used=324, radius=4, mask=576, ctx=768),
+    'small': dict(hdim=96, cdim=64, x_ld=160, flow_slot=144, corr_ld=224, corr_used=196, radius=3, mask=0, ctx=0),
 }
 
 
@@ -44,9 +44,12 @@ class UpdateState:
         self.delta = torch.empty((B, h, w, 2), **f)
         self.mask = torch.empty((B, h, w, max(g['mask'], 1)), **f)
         self.ws = torch.empty((ws,), **f)
+        # loop-invariant GRU context terms (raft_gru_context_f32); SmallRAFT does not use them
+        self.ctx = torch.empty((B, h, w, g['ctx']) if g['ctx'] else (4,), **f)
         self.c = _ffi.State(net=_dev.ptr(self.net), x=_dev.ptr(self.x), corr=_dev.ptr(self.corr),
                             coords1=_dev.ptr(self.coords1), flow=_dev.ptr(self.flow),
-                            delta=_dev.ptr(self.delta), mask=_dev.ptr(self.mask), ws=_dev.ptr(self.ws))
+                            delta=_dev.ptr(self.delta), mask=_dev.ptr(self.mask), ws=_dev.ptr(self.ws),
+                            ctx=_dev.ptr(self.ctx))
         assert M > 0
 
 
@@ -110,9 +113,13 @@ class _UpdateBlock:
         ys, xs = torch.meshgrid(torch.arange(h, device=net.device, dtype=torch.float32),
                                 torch.arange(w, device=net.device, dtype=torch.float32), indexing='ij')
         st.coords1.copy_(torch.stack([xs, ys], dim=-1).unsqueeze(0) + flow)
+        self.prepare(st)
         self.step(st)
         mask = _dev.wrap(st.mask) if g['mask'] else None
         return _dev.wrap(st.net), mask, _dev.wrap(st.delta)
+
+    def prepare(self, st: UpdateState) -> None:
+        """Loop-invariant work that depends on ``inp`` only (once per forward, before the first ``step``)."""
 
     def step(self, st: UpdateState) -> None:
         raise NotImplementedError
@@ -128,6 +135,10 @@ class BasicUpdateBlock(_UpdateBlock):
 
     def _pack(self, weights):
         return packing.pack_basic_update(weights, self.prefix)
+
+    def prepare(self, st):
+        check(_dev.lib().raft_gru_context_f32(C.byref(self.c), st.B, st.h, st.w, C.byref(st.c),
+                                              _dev.stream_ptr()), 'gru_context')
 
     def step(self, st):
         check(_dev.lib().raft_update_basic_f32(C.byref(self.c), st.B, st.h, st.w, C.byref(st.c),

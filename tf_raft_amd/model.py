@@ -110,6 +110,7 @@ class RAFT:
     def _prepare(self, cnet, st):
         check(_dev.lib().raft_prepare_state_f32(_dev.ptr(cnet), st.B, st.h, st.w, C.byref(st.c),
                                                 _dev.stream_ptr()), 'prepare_state')
+        self.update_block.prepare(st)          # GRU terms of `inp`: constant over the loop (model.py:86)
 
     def _iterate(self, corr: CorrBlock, st, iters, flow_up):
         if self.overlap:

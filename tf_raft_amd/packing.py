@@ -71,19 +71,27 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
                 np.asarray(w[f'{p}/encoder/convf1/bias'], dtype=np.float32), 128))
     conv('convf2', f'{p}/encoder/convf2')
     conv('conv', f'{p}/encoder/conv')
+    # SepConvGRU: the `inp` rows (128:256 of hx) of z / r / q go to the loop-invariant context
+    # convolution gru_ctx{s} together with the biases; the per-iteration kernels keep [h | motion | flow]
+    loop_rows = np.r_[0:128, 256:384]
+    ctx = []
     for s in ('1', '2'):
         k, b = fuse_n(w, [f'{p}/gru/convz{s}', f'{p}/gru/convr{s}'])
-        wp, bb, npad = pack_conv(k, b, [(128, 128), (256, 256)])
+        wp, bb, npad = pack_conv(k[:, :, loop_rows, :], np.zeros_like(b), [(128, 128), (128, 128)])
         out.append((f'gru_zr{s}', wp, bb, npad))
-        wp, bb, npad = pack_conv(w[f'{p}/gru/convq{s}/kernel'], w[f'{p}/gru/convq{s}/bias'], [(128, 128), (256, 256)])
+        kq, bq = w[f'{p}/gru/convq{s}/kernel'], w[f'{p}/gru/convq{s}/bias']
+        wp, bb, npad = pack_conv(kq[:, :, loop_rows, :], np.zeros_like(bq), [(128, 128), (128, 128)])
         out.append((f'gru_q{s}', wp, bb, npad))
+        kc = np.concatenate([k, kq], axis=3)[:, :, 128:256, :]
+        wp, bb, npad = pack_conv(kc, np.concatenate([b, bq]))
+        ctx.append((f'gru_ctx{s}', wp, bb, npad))
     k, b = fuse_n(w, [f'{p}/flow_head/conv1', f'{p}/mask/0'])
     wp, bb, npad = pack_conv(k, b)
     out.append(('fh1_mask0', wp, bb, npad))
     out.append(('fh2', np.ascontiguousarray(w[f'{p}/flow_head/conv2/kernel'], dtype=np.float32).reshape(9, 256, 2),
                 np.asarray(w[f'{p}/flow_head/conv2/bias'], dtype=np.float32), 2))
     conv('mask2', f'{p}/mask/2')
-    return out
+    return out + ctx
 
 
 def pack_small_update(weights: Dict[str, np.ndarray], prefix: str = 'update_block'):

@@ -16,8 +16,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 H, W = 56, 64
 LAYERS = [  # name, kh, kw, cin(real), cin(pad), cout
     ('convc1', 1, 1, 324, 352, 256), ('convc2', 3, 3, 256, 256, 192), ('convf2', 3, 3, 128, 128, 64),
-    ('conv', 3, 3, 256, 256, 126), ('gru_zr', 1, 5, 384, 384, 256), ('gru_q', 1, 5, 384, 384, 128),
-    ('gru_zr_v', 5, 1, 384, 384, 256), ('fh1_mask0', 3, 3, 128, 128, 512), ('mask2', 1, 1, 256, 256, 576)]
+    ('conv', 3, 3, 256, 256, 126), ('gru_zr', 1, 5, 256, 256, 256), ('gru_q', 1, 5, 256, 256, 128),
+    ('gru_zr_v', 5, 1, 256, 256, 256), ('gru_q_v', 5, 1, 256, 256, 128), ('gru_ctx', 1, 5, 128, 128, 384), ('fh1_mask0', 3, 3, 128, 128, 512), ('mask2', 1, 1, 256, 256, 576)]
 rng = np.random.default_rng(0)
 lib = _dev.lib()
 print(f'B={B} M={B*H*W}')
