@@ -59,6 +59,35 @@ def stage_work(B, h, w):
     return flops, bytes_
 
 
+def measured_copy_gbs(device, lib, _dev, check, floats=1 << 28, reps=10):
+    """HBM copy bandwidth of THIS box (read + write bytes / time) with the library's 16-byte-per-lane streaming
+    copy: 2 x 1 GiB buffers (4x the 256 MiB Infinity Cache), HIP events on the launch stream."""
+    src = torch.empty(floats, device=device, dtype=torch.float32).normal_()
+    dst = torch.empty_like(src)
+    run = lambda: check(lib.raft_stream_copy_f32(_dev.ptr(src), _dev.ptr(dst), floats, _dev.stream_ptr()), 'stream_copy')
+    for _ in range(2):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * 4.0 * floats * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md section
+    HBM: gfx950 tallies 128-byte requests at 64 bytes).  None when no pass covers the kernel."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            t = json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -167,22 +196,45 @@ def main():
         stage_ms = {k: round(float(v), 5) for k, v in zip(STAGES, per_launch_ms)}
         flops, bytes_ = stage_work(B, h, w)
         dom = STAGES[int(np.argmax(acc))]
+        copy_gbs = measured_copy_gbs(device, _dev.lib(), _dev, _ffi.check)
+        result['hbm_copy_gbs_measured'] = round(copy_gbs, 1)
+
+        def traffic_of(name):
+            t = pmc_traffic(name)
+            if not t or t.get('batch') != B:
+                return None, None
+            return t['hbm_bytes_per_launch'], t
         if dom in flops:
             ach = flops[dom] / (stage_ms[dom] * 1e-3) / 1e12
+            tr, note = traffic_of(dom)
             roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
-                    'flops_per_launch': flops[dom], 'ms_per_launch': stage_ms[dom]}
+                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': tr,
+                    'flops_per_launch': flops[dom], 'ms_per_launch': stage_ms[dom], 'traffic_source': note}
         else:
             ach = bytes_[dom] / (stage_ms[dom] * 1e-3) / 1e9
+            tr, note = traffic_of(dom)
             roof = {'kernel': dom, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
-                    'bytes_per_launch': bytes_[dom], 'ms_per_launch': stage_ms[dom]}
+                    'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': tr,
+                    'bytes_per_launch': bytes_[dom], 'ms_per_launch': stage_ms[dom], 'traffic_source': note}
         result['roofline'] = roof
-        lk = bytes_['corr_lookup'] / (stage_ms['corr_lookup'] * 1e-3) / 1e9
-        result['roofline_corr_lookup'] = {
-            'kernel': 'corr_lookup', 'bound': 'hbm', 'achieved': round(lk, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-            'frac': round(lk / PEAK_HBM_GBS, 4), 'traffic': None, 'bytes_per_launch': bytes_['corr_lookup'],
-            'ms_per_launch': stage_ms['corr_lookup']}
+        # the HBM-bound kernels the north star singles out: per-launch algorithmic bytes / HIP-event time, against the
+        # 8 TB/s datasheet peak (frac) and against this box's measured copy bandwidth (frac_of_measured_copy)
+        for name in ('corr_lookup', 'upsample_convex'):
+            gbs = bytes_[name] / (stage_ms[name] * 1e-3) / 1e9
+            tr, note = traffic_of(name)
+            result['roofline_' + name] = {
+                'kernel': name, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': round(gbs / PEAK_HBM_GBS, 4), 'frac_of_measured_copy': round(gbs / copy_gbs, 4),
+                'traffic': tr, 'bytes_per_launch': bytes_[name], 'ms_per_launch': stage_ms[name],
+                'traffic_source': note}
+        build_bytes = B * (2 * h * w * 256 * 4) + 4 * (corr._off[4])     # fmaps read + tiled pyramid written
+        gbs = build_bytes / (pre_ms['corr_build'] * 1e-3) / 1e9
+        result['roofline_corr_build'] = {
+            'kernel': 'corr_build (fmap pyramid + corr_gemm)', 'bound': 'hbm', 'achieved': round(gbs, 1),
+            'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+            'frac_of_measured_copy': round(gbs / copy_gbs, 4), 'traffic': None, 'bytes_per_launch': build_bytes,
+            'ms_per_launch': round(pre_ms['corr_build'], 4),
+            'note': 'fp32-MFMA GEMM: 26.5 GFLOP at B=4 bound it at >= 0.17 ms (157.3 TF), below the HBM-write bound'}
         mfma_ms = sum(stage_ms[k] for k in flops)
         result['update_block_tflops'] = round(sum(flops.values()) / (mfma_ms * 1e-3) / 1e12, 2)
         result['stage_ms'] = stage_ms

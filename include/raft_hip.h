@@ -43,10 +43,15 @@ const char *raft_error_string(int rc);
 
 /* ------------------------------------------------------------------ correlation volume */
 
-/* Pyramid geometry.  Level l holds, for each of the B*h*w query pixels, an (lh[l], lw[l])
- * row-major map; lh/lw follow tf.nn.avg_pool2d(2, 2, 'VALID') (floor).  level_offsets[l] is
- * the float offset of level l inside one allocation, level_offsets[levels] the total float
- * count.  Host-only helper (no GPU work).  reference corr.py:106-114. */
+/* Pyramid geometry.  Level l holds, for each of the B*h*w query pixels, an (lh[l], lw[l]) map;
+ * lh/lw follow tf.nn.avg_pool2d(2, 2, 'VALID') (floor).  A map is stored as 4x8 tiles of 32
+ * floats (one 128-byte line each), tiles row-major, padded to whole tiles:
+ *   map_floats(l) = ceil(lh/4) * ceil(lw/8) * 32,
+ *   element (y, x) at ((y/4) * ceil(lw/8) + x/8) * 32 + (y%4) * 8 + x%8     (padding is zero),
+ * so that the (2r+2)^2 lookup footprint pulls ~7 lines of a large map instead of ~13.
+ * level_offsets[l] is the float offset of level l inside one allocation (level l = B*h*w maps
+ * back to back), level_offsets[levels] the total float count.  Host-only helper (no GPU work).
+ * reference corr.py:106-114. */
 int raft_corr_pyramid_layout(int B, int h, int w, int levels,
                              int64_t *level_offsets /* [levels+1] */,
                              int *lh /* [levels] */, int *lw /* [levels] */);
@@ -58,7 +63,8 @@ int64_t raft_corr_build_workspace_floats(int B, int h, int w, int C, int levels)
  * Replaces CorrBlock.__init__ / CorrBlock.correlation (reference corr.py:100-114, 154-162):
  *   corr[b, q, t] = <fmap1[b, q, :], fmap2[b, t, :]> / sqrt(C), then 3x avg_pool2d over t.
  * fmap1, fmap2: (B, h, w, C).  pyr: float[level_offsets[levels]]; level l is laid out
- * (B*h*w, lh[l], lw[l]) row-major == the reference's corr_pyramid[l] with its trailing 1 dropped.
+ * (B*h*w, map_floats(l)) in the tiled map layout above == the reference's corr_pyramid[l]
+ * (B*h*w, lh[l], lw[l], 1) after un-tiling.
  * Levels > 0 are computed as <fmap1, avgpool_l(fmap2)> / sqrt(C) (average pooling over the
  * target dims commutes with the dot product); `workspace` holds the pooled fmap2 pyramid. */
 int raft_corr_build_f32(const float *fmap1, const float *fmap2, int B, int h, int w, int C,
@@ -105,6 +111,12 @@ int raft_upsample_convex_f32(const float *flow, const float *mask, int B, int h,
 /* upflow8 (reference corr.py:93-96): 8 * tf.image.resize(flow, (8h, 8w), 'bilinear')
  * with TF2 half-pixel centres.  flow: (B, h, w, 2); out: (B, 8h, 8w, 2). */
 int raft_upflow8_f32(const float *flow, int B, int h, int w, float *out, void *stream);
+
+/* Measurement utility (no reference counterpart): 16-byte-per-lane streaming copy of n floats
+ * (n % 4 == 0, 16-byte aligned pointers).  bench.py times it to state the HBM copy bandwidth of
+ * the box it runs on -- the "measured roofline" the lookup / build / upsample kernels are quoted
+ * against next to the 8 TB/s datasheet figure. */
+int raft_stream_copy_f32(const float *src, float *dst, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------ convolutions */
 

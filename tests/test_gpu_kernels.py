@@ -105,13 +105,16 @@ def _device_corr_with_oracle_pyramid(f1, f2, levels, radius):
     dev = CorrBlock(f1, f2, num_levels=levels, radius=radius)
     ref = oracle.CorrBlock(_t(f1), _t(f2), num_levels=levels, radius=radius)
     for l in range(levels):
-        n = ref.corr_pyramid[l].numel()
-        dev._pyr[dev._off[l]:dev._off[l] + n].copy_(ref.corr_pyramid[l].reshape(-1).to(dev._pyr.device))
+        dev._set_level(l, ref.corr_pyramid[l])
+        assert torch.equal(dev.corr_pyramid[l].cpu(), ref.corr_pyramid[l])     # tile / un-tile round trip
     return dev, ref
 
 
-@pytest.mark.parametrize('radius,shape', [(4, (2, 8, 12, 64)), (3, (1, 16, 24, 32)), (4, (1, 56, 64, 32))])
-def test_corr_lookup_bit_exact_vs_oracle(rng, radius, shape):
+@pytest.mark.parametrize('staged', ['0', '1'])   # strip kernel: direct stores / rows transposed through LDS
+@pytest.mark.parametrize('radius,shape', [(4, (2, 8, 12, 64)), (3, (1, 16, 24, 32)), (4, (1, 56, 64, 32)),
+                                          (4, (1, 14, 20, 32))])
+def test_corr_lookup_bit_exact_vs_oracle(rng, radius, shape, staged, monkeypatch):
+    monkeypatch.setenv('RAFT_LOOKUP_STAGED', staged)
     B, h, w, C = shape
     f1 = rng.normal(size=shape).astype(np.float32)
     f2 = rng.normal(size=shape).astype(np.float32)
@@ -135,6 +138,20 @@ def test_corr_lookup_bit_exact_vs_oracle(rng, radius, shape):
     # on the integer grid the level-0 window is identically zero
     got0 = _np(dev.retrieve(grid))
     assert np.all(got0[..., :(2 * radius + 1) ** 2] == 0.0)
+
+
+def test_corr_lookup_three_levels(rng):
+    """num_levels = 3: the strips of the fourth level idle, direct stores."""
+    B, h, w, C, r = 1, 8, 12, 32, 4
+    f1 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    f2 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    dev, ref = _device_corr_with_oracle_pyramid(f1, f2, 3, r)
+    import oracle
+    coords = oracle.coords_grid(B, h, w).numpy() + rng.normal(scale=2.0, size=(B, h, w, 2)).astype(np.float32)
+    got = _np(dev.retrieve(coords))
+    want = ref.retrieve(_t(coords)).numpy()
+    assert got.shape == want.shape == (B, h, w, 3 * 81)
+    np.testing.assert_array_equal(got, want)
 
 
 def test_corr_lookup_axis_quirk(rng):

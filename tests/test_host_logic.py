@@ -239,13 +239,31 @@ def test_pyramid_layout_host_helper():
     assert lib.raft_corr_pyramid_layout(1, 56, 64, 4, off, lh, lw) == 0
     assert list(lh) == [56, 28, 14, 7] and list(lw) == [64, 32, 16, 8]        # reference corr.py:112-114
     n = 56 * 64
-    assert list(off) == [0, n * n, n * n + n * 896, n * n + n * (896 + 224), n * (n + 896 + 224 + 56)]
+    # per-query maps are stored as 4x8 tiles padded to whole tiles: 14x16 -> 4x2 tiles = 256, 7x8 -> 2x1 tiles = 64
+    assert list(off) == [0, n * n, n * n + n * 896, n * n + n * (896 + 256), n * (n + 896 + 256 + 64)]
     assert lib.raft_corr_pyramid_layout(4, 8, 12, 4, off, lh, lw) == 0         # reference test size 64x96
     assert list(lh) == [8, 4, 2, 1] and list(lw) == [12, 6, 3, 1]
+    nq = 4 * 8 * 12
+    assert list(off) == [0, nq * 128, nq * (128 + 32), nq * (128 + 64), nq * (128 + 96)]
     assert lib.raft_corr_pyramid_layout(1, 4, 4, 4, off, lh, lw) == -2         # pooled away: RAFT_E_SHAPE
     assert lib.raft_corr_pyramid_layout(1, 8, 8, 5, off, lh, lw) == -3         # RAFT_E_UNSUPPORTED
-    assert lib.raft_corr_build_workspace_floats(2, 56, 64, 256, 4) == 2 * 4760 * 256
+    assert lib.raft_corr_build_workspace_floats(2, 56, 64, 256, 4) == 2 * 4800 * 256    # tile-padded rows
     assert lib.raft_update_workspace_floats(4, 56, 64) == 4 * 3584 * 1408
+
+
+def test_tiled_map_layout_round_trip():
+    """tile_maps / untile_maps (host mirror of common.h raft_tiled_index) on ragged sizes."""
+    from tf_raft_amd.layers.corr import tile_maps, untile_maps
+    g = torch.Generator().manual_seed(0)
+    for h, w in [(56, 64), (14, 16), (7, 8), (3, 5), (1, 1), (5, 17)]:
+        m = torch.rand((3, h, w), generator=g)
+        t = tile_maps(m)
+        ty, tx = (h + 3) // 4, (w + 7) // 8
+        assert t.shape == (3, ty * tx * 32)
+        assert torch.equal(untile_maps(t, h, w), m)
+        y, x = h - 1, w - 1                                                     # the documented element formula
+        assert t[1, ((y // 4) * tx + x // 8) * 32 + (y % 4) * 8 + x % 8] == m[1, y, x]
+        assert float(t.sum()) == pytest.approx(float(m.sum()), rel=1e-6)        # padding is zero
 
 
 def test_argument_errors_are_returned_before_any_device_work():

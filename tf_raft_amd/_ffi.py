@@ -62,6 +62,7 @@ _SIGNATURES = {
     'raft_coords_grid_f32': (_I, [_P, _I, _I, _I, _P]),
     'raft_upsample_convex_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'raft_upflow8_f32': (_I, [_P, _I, _I, _I, _P, _P]),
+    'raft_stream_copy_f32': (_I, [_P, _P, C.c_int64, _P]),
     'raft_conv2d_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I,
                              C.c_float, _P, _I, _P]),
     'raft_update_workspace_floats': (C.c_int64, [_I, _I, _I]),

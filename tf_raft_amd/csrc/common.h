@@ -32,10 +32,24 @@ static inline bool raft_aligned16(const void *p) { return (((uintptr_t)p) & 15u)
 
 static inline int raft_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Layout of one per-query correlation map (and of the rows of the pooled fmap2 pyramid): 4 x 8 tiles of 32
+// floats = one 128-byte line each, tiles row-major, maps padded to whole tiles.  The (2r+2)^2 lookup footprint
+// then touches ~6.9 lines of a large map instead of ~12.8 with row-major rows (the lookup is
+// bound by the lines it pulls from HBM, not by the 40 useful bytes per footprint row).
+constexpr int RAFT_TILE_H = 4, RAFT_TILE_W = 8, RAFT_TILE_FLOATS = 32;
+__host__ __device__ inline int raft_tiles_x(int w) { return (w + RAFT_TILE_W - 1) / RAFT_TILE_W; }
+__host__ __device__ inline int raft_tiles_y(int h) { return (h + RAFT_TILE_H - 1) / RAFT_TILE_H; }
+__host__ __device__ inline int raft_map_floats(int h, int w) { return raft_tiles_y(h) * raft_tiles_x(w) * RAFT_TILE_FLOATS; }
+__host__ __device__ inline int raft_tiled_index(int y, int x, int tiles_x) {
+    return (((y >> 2) * tiles_x + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
+}
+
 struct PyramidGeom {
     int64_t off[RAFT_MAX_LEVELS];   // float offset of each level of the corr pyramid
     int lh[RAFT_MAX_LEVELS];
     int lw[RAFT_MAX_LEVELS];
+    int tx[RAFT_MAX_LEVELS];        // tiles per tile-row of a level's map
+    int map[RAFT_MAX_LEVELS];       // floats per query map (padded to whole tiles)
     int levels;
 };
 
@@ -43,10 +57,17 @@ static inline int raft_make_geom(int h, int w, int levels, const int64_t *level_
     if (levels < 1 || levels > RAFT_MAX_LEVELS) return RAFT_E_UNSUPPORTED;
     g->levels = levels;
     int ch = h, cw = w;
+    for (int l = 0; l < RAFT_MAX_LEVELS; ++l) {
+        g->lh[l] = g->lw[l] = g->tx[l] = 1;
+        g->map[l] = RAFT_TILE_FLOATS;
+        g->off[l] = 0;
+    }
     for (int l = 0; l < levels; ++l) {
         if (ch < 1 || cw < 1) return RAFT_E_SHAPE;   // pooled away: the reference would fail here too
         g->lh[l] = ch;
         g->lw[l] = cw;
+        g->tx[l] = raft_tiles_x(cw);
+        g->map[l] = raft_map_floats(ch, cw);
         g->off[l] = level_offsets ? level_offsets[l] : 0;
         ch /= 2;
         cw /= 2;

@@ -1,9 +1,10 @@
 // Correlation volume build + pyramid lookup for gfx950 (MI355X).
 //
 //   raft_corr_build_f32   : fp32 MFMA "NT" GEMM  fmap1 (N x C) . fmap2_pyr (T x C)^T / sqrt(C),
-//                           T = sum over levels of lh*lw (pooled fmap2), written straight into the
-//                           per-level (B*N, lh, lw) maps.   [reference corr.py:100-114, 154-162]
-//   raft_corr_lookup_f32  : one wavefront per query pixel; the (2r+2)^2 footprint of each level is
+//                           T = sum over levels of the tile-padded map sizes (pooled fmap2, rows in
+//                           tile order), written straight into the per-level (B*N, map_l) maps of
+//                           4x8-tiled floats.                [reference corr.py:100-114, 154-162]
+//   raft_corr_lookup_f32  : 36 threads per query pixel; the (2r+2)^2 footprint of each level is
 //                           staged in LDS, the (2r+1)^2 window is evaluated from it and written as
 //                           contiguous channels.              [reference corr.py:116-152, 28-69]
 //   raft_bilinear_sampler_f32, raft_coords_grid_f32           [reference corr.py:28-69, 72-90]
@@ -28,9 +29,7 @@ extern "C" int raft_corr_pyramid_layout(int B, int h, int w, int levels, int64_t
         level_offsets[l] = off;
         if (lh) lh[l] = ch;
         if (lw) lw[l] = cw;
-        int64_t sz = nq * ch * cw;
-        sz = (sz + 3) & ~(int64_t)3;   // keep every level 16-byte aligned
-        off += sz;
+        off += nq * raft_map_floats(ch, cw);   // whole 128-byte tiles: every map starts on a line
         ch /= 2;
         cw /= 2;
     }
@@ -41,7 +40,7 @@ extern "C" int raft_corr_pyramid_layout(int B, int h, int w, int levels, int64_t
 static int64_t pyr_cols(int h, int w, int levels) {
     int64_t t = 0;
     for (int l = 0; l < levels; ++l) {
-        t += (int64_t)h * w;
+        t += raft_map_floats(h, w);
         h /= 2;
         w /= 2;
     }
@@ -54,37 +53,46 @@ extern "C" int64_t raft_corr_build_workspace_floats(int B, int h, int w, int C, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// fmap2 feature pyramid: level l = 2x2 VALID average of level l-1 (NHWC, channels vectorised x4)
-// workspace layout per batch element: [level0 (h*w rows) | level1 | ...] x C floats
+// fmap2 feature pyramid: level l = 2x2 VALID average of level l-1 (NHWC, channels vectorised x4).
+// Workspace layout per batch element: [level0 | level1 | ...] x C floats, the rows (target positions) of a
+// level in the TILED order of its correlation map (raft_tiled_index), padded positions zero: column n of the
+// GEMM below is then float n of the tiled per-query map, so the GEMM epilogue writes whole 128-byte tiles.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) fmap_copy_level0_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
-                                                               int64_t rows_per_b, int64_t tot_rows_per_b, int c4,
-                                                               int64_t total) {
+__global__ void __launch_bounds__(256) fmap_tile_level0_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
+                                                               int h, int w, int tiles_x, int map, int64_t tot_rows_per_b,
+                                                               int c4, int64_t total) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    int64_t per_b = rows_per_b * c4;
-    int64_t b = i / per_b, r = i % per_b;
-    dst[b * tot_rows_per_b * c4 + r] = src[i];
+    const int c = (int)(i % c4);
+    int64_t r = i / c4;
+    const int n = (int)(r % map);
+    const int64_t b = r / map;
+    const int t = n >> 5, y = (t / tiles_x) * 4 + ((n >> 3) & 3), x = (t % tiles_x) * 8 + (n & 7);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y < h && x < w) v = src[((b * h + y) * (int64_t)w + x) * c4 + c];
+    dst[(b * tot_rows_per_b + n) * c4 + c] = v;
 }
 
 __global__ void __launch_bounds__(256) fmap_pool_kernel(f32x4 *__restrict__ ws, int64_t tot_rows_per_b, int c4,
-                                                        int64_t src_off, int sh, int sw, int64_t dst_off, int dh,
-                                                        int dw, int64_t total) {
-    (void)sh;
+                                                        int64_t src_off, int stx, int64_t dst_off, int dh, int dw,
+                                                        int dtx, int dmap, int64_t total) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    int c = (int)(i % c4);
-    int64_t p = i / c4;
-    int x = (int)(p % dw);
-    int y = (int)((p / dw) % dh);
-    int64_t b = p / ((int64_t)dw * dh);
-    const f32x4 *s = ws + (b * tot_rows_per_b + src_off) * c4;
-    f32x4 v00 = s[((int64_t)(2 * y) * sw + 2 * x) * c4 + c];
-    f32x4 v01 = s[((int64_t)(2 * y) * sw + 2 * x + 1) * c4 + c];
-    f32x4 v10 = s[((int64_t)(2 * y + 1) * sw + 2 * x) * c4 + c];
-    f32x4 v11 = s[((int64_t)(2 * y + 1) * sw + 2 * x + 1) * c4 + c];
-    f32x4 r = ((v00 + v01) + (v10 + v11)) * 0.25f;
-    ws[(b * tot_rows_per_b + dst_off + (int64_t)y * dw + x) * c4 + c] = r;
+    const int c = (int)(i % c4);
+    int64_t r = i / c4;
+    const int n = (int)(r % dmap);
+    const int64_t b = r / dmap;
+    const int t = n >> 5, y = (t / dtx) * 4 + ((n >> 3) & 3), x = (t % dtx) * 8 + (n & 7);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (y < dh && x < dw) {
+        const f32x4 *s = ws + (b * tot_rows_per_b + src_off) * c4 + c;
+        f32x4 v00 = s[(int64_t)raft_tiled_index(2 * y, 2 * x, stx) * c4];
+        f32x4 v01 = s[(int64_t)raft_tiled_index(2 * y, 2 * x + 1, stx) * c4];
+        f32x4 v10 = s[(int64_t)raft_tiled_index(2 * y + 1, 2 * x, stx) * c4];
+        f32x4 v11 = s[(int64_t)raft_tiled_index(2 * y + 1, 2 * x + 1, stx) * c4];
+        o = ((v00 + v01) + (v10 + v11)) * 0.25f;
+    }
+    ws[(b * tot_rows_per_b + dst_off + n) * c4 + c] = o;
 }
 
 extern "C" int raft_fmap_pyramid_f32(const float *fmap2, int B, int h, int w, int C, int levels,
@@ -99,19 +107,22 @@ extern "C" int raft_fmap_pyramid_f32(const float *fmap2, int B, int h, int w, in
     const int c4 = C / 4;
     const int64_t tot = pyr_cols(h, w, levels);
     {
-        int64_t total = (int64_t)B * h * w * c4;
-        fmap_copy_level0_kernel<<<raft_ceil_div(total, 256), 256, 0, s>>>(
-            (const f32x4 *)fmap2, (f32x4 *)fmap2_pyr, (int64_t)h * w, tot, c4, total);
+        const int map = raft_map_floats(h, w);
+        int64_t total = (int64_t)B * map * c4;
+        fmap_tile_level0_kernel<<<raft_ceil_div(total, 256), 256, 0, s>>>(
+            (const f32x4 *)fmap2, (f32x4 *)fmap2_pyr, h, w, raft_tiles_x(w), map, tot, c4, total);
     }
     int64_t src_off = 0;
     int sh = h, sw = w;
     for (int l = 1; l < levels; ++l) {
         int dh = sh / 2, dw = sw / 2;
         RAFT_REQUIRE(dh >= 1 && dw >= 1, RAFT_E_SHAPE);
-        int64_t dst_off = src_off + (int64_t)sh * sw;
-        int64_t total = (int64_t)B * dh * dw * c4;
-        fmap_pool_kernel<<<raft_ceil_div(total, 256), 256, 0, s>>>((f32x4 *)fmap2_pyr, tot, c4, src_off, sh, sw,
-                                                                    dst_off, dh, dw, total);
+        int64_t dst_off = src_off + raft_map_floats(sh, sw);
+        const int dmap = raft_map_floats(dh, dw);
+        int64_t total = (int64_t)B * dmap * c4;
+        fmap_pool_kernel<<<raft_ceil_div(total, 256), 256, 0, s>>>((f32x4 *)fmap2_pyr, tot, c4, src_off,
+                                                                    raft_tiles_x(sw), dst_off, dh, dw,
+                                                                    raft_tiles_x(dw), dmap, total);
         src_off = dst_off;
         sh = dh;
         sw = dw;
@@ -222,7 +233,7 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
 #pragma unroll
         for (int l = 1; l < RAFT_MAX_LEVELS; ++l)
             if (l < p.g.levels && n >= p.col_off[l]) lvl = l;
-        const int64_t map = (int64_t)p.g.lh[lvl] * p.g.lw[lvl];
+        const int64_t map = p.g.map[lvl];     // column n - col_off = float index inside the tiled map
         float *base = p.pyr + p.g.off[lvl] + (int64_t)b * p.N * map + (n - p.col_off[lvl]);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -260,7 +271,7 @@ extern "C" int raft_corr_build_f32(const float *fmap1, const float *fmap2, int B
     for (int l = 0; l < RAFT_MAX_LEVELS + 1; ++l) a.col_off[l] = 0;
     for (int l = 0; l < levels; ++l) {
         a.col_off[l] = t;
-        t += (int64_t)a.g.lh[l] * a.g.lw[l];
+        t += a.g.map[l];
     }
     a.col_off[levels] = t;
     a.T = (int)t;
@@ -282,240 +293,192 @@ struct LookupArgs {
     int ld_out;
 };
 
-// v1 (default): the 2 x levels x (2r+1) axis taps {i0, i1, w0, w1} are evaluated ONCE per query by
-// 72 lanes and parked in LDS next to the footprint; every output then needs two 16-B tap reads,
-// four footprint reads and seven flops.  (v0 below recomputes four axis taps per output and is
-// VALU-issue bound; it is kept for A/B timing: RAFT_LOOKUP_V0=1.)
+// Strip kernel.  SP = 4 * (2r+1) threads serve one query from start to finish (r = 4: 36 threads per query,
+// QB = 7 queries per 256-thread workgroup), so every index decomposition is a compile-time constant of the
+// thread and nothing is looked up through tables:
+//   * the thread loads its query's coordinate, derives the footprint origins of the levels in registers and
+//     issues its 12 clamped footprint gathers at once (one dependent load after the coordinate, no barrier
+//     first); the maps are 4x8-tiled (common.h), so a footprint pulls ~7 lines of a large map, not ~13;
+//   * under those loads it evaluates the x tap and the y tap of its own (level, offset) pair
+//     {i0 - origin, i1 - origin, w0, w1} as LDS byte offsets; the x tap stays in registers (the same thread
+//     consumes it), the y tap goes to LDS; then the gathered footprint values are parked in LDS; ONE barrier;
+//   * it then owns the strip (level l, x-offset a) = 2r+1 consecutive output channels: per output one
+//     broadcast y-tap read, four footprint reads, 4 + 7 flops in the reference's order (bit-exact).
+// STAGE 0: each thread stores its strip directly (2r+1 dwords, 4(2r+1) bytes apart across lanes);
+// STAGE 1: the strips are transposed through LDS (aliasing the footprints, two more barriers) and written as
+//          whole rows of 16-byte stores (needs levels == 4, ld_out % 4 == 0, a 16-byte aligned `out`).
+// LDS = QB * (4 * FP * 4 + SP * 16) bytes = 15.2 KB at r = 4 and 58 VGPRs: 8 workgroups per CU, so a 448x512
+// batch of 4 (2048 workgroups) is resident in a single round.  History (profiles/r03*): a table-driven
+// 7-queries-per-workgroup kernel ran 18.6 us at B = 4 (854 VALU instructions per wave, 7 workgroups per CU);
+// this one 12.0-12.9 us (367); a double-buffered multi-batch variant of it measured no better (13.4 us): the
+// kernel is bound by the lines its gathers pull, not by phase lock-step.
+#ifndef RAFT_LOOKUP_ABL
+#define RAFT_LOOKUP_ABL 0   // tools/ablate/lookup_abl.hip builds this file with pieces of the kernel switched off
+#endif
+
 template <int R>
-__global__ void __launch_bounds__(256) corr_lookup_kernel(LookupArgs p) {
-#pragma clang fp contract(off)   // keep mul/add unfused: same roundings as the unfused reference ops
-    constexpr int D = 2 * R + 1, FW = 2 * R + 2, FP = FW * FW, NT = RAFT_MAX_LEVELS * 2 * D;
-    __shared__ float sfp[4][RAFT_MAX_LEVELS][FP];
-    __shared__ __attribute__((aligned(16))) int stap[4][NT + 8][4];   // {i0 - origin, i1 - origin, w0, w1}
-    __shared__ int sorg[4][RAFT_MAX_LEVELS][2];                        // footprint origin (x, y) per level
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
-    const bool active = q < p.nq;
-    const int levels = p.g.levels;
-    float cx0 = 0.f, cy0 = 0.f;
-    if (active) {
-        cx0 = p.coords[2 * q];
-        cy0 = p.coords[2 * q + 1];
-        // ---- axis taps: entry t = (l*2 + axis)*D + d
-        for (int t = lane; t < levels * 2 * D; t += 64) {
-            const int l = t / (2 * D), r = t - l * (2 * D);
-            const int axis = r / D, d = r - axis * D;
-            const float sc = 1.0f / (float)(1 << l);   // exact power of two: x * sc == x / 2^l
-            const int size = axis ? p.g.lh[l] : p.g.lw[l];
-            const float c = (axis ? cy0 : cx0) * sc;
-            const AxisTap org = axis_tap(c, -R, size), tp = axis_tap(c, d - R, size);
-            stap[wave][t][0] = tp.i0 - org.i0;
-            stap[wave][t][1] = tp.i1 - org.i0;
-            stap[wave][t][2] = __float_as_int(tp.w0);
-            stap[wave][t][3] = __float_as_int(tp.w1);
-            if (d == 0) sorg[wave][l][axis] = org.i0;
-        }
-    }
-    __syncthreads();
-    if (active) {
-        // ---- footprint staging: (fy, fx) of this lane's two footprint slots do not depend on the level
-        const int i1 = lane + 64;
-        const int fy0 = lane / FW, fx0 = lane - fy0 * FW;
-        const int fy1 = i1 / FW, fx1 = i1 - fy1 * FW;
+struct StripCfg {
+    static constexpr int L = 4, D = 2 * R + 1, FW = 2 * R + 2, FP = FW * FW, SP = L * D, QB = 256 / SP;
+    static constexpr int NR = (FP + SP - 1) / SP, NOUT = L * D * D;
+};
+
+// origins of the footprints + the clamped gathers of this thread's slots (all issued back to back)
+template <int R>
+__device__ __forceinline__ void strip_gather(const LookupArgs &p, int64_t q0, int qc, float2 cq, int j,
+                                             float (&v)[4][StripCfg<R>::NR], int (&org)[4][2]) {
+    using G = StripCfg<R>;
+    int fyx[G::NR];
 #pragma unroll
-        for (int l = 0; l < RAFT_MAX_LEVELS; ++l) {
-            if (l >= levels) break;
-            const int w = p.g.lw[l], h = p.g.lh[l];
-            const int ox = sorg[wave][l][0], oy = sorg[wave][l][1];
-            const float *img = p.pyr + p.g.off[l] + q * ((int64_t)h * w);
-            sfp[wave][l][lane] = img[min(oy + fy0, h - 1) * w + min(ox + fx0, w - 1)];
-            if (i1 < FP) sfp[wave][l][i1] = img[min(oy + fy1, h - 1) * w + min(ox + fx1, w - 1)];
-        }
+    for (int r = 0; r < G::NR; ++r) {
+        const int s = min(j + G::SP * r, G::FP - 1);
+        fyx[r] = ((s / G::FW) << 8) | (s % G::FW);
     }
-    __syncthreads();
-    if (!active) return;
-    const int nout = levels * D * D;
-    float *o = p.out + q * (int64_t)p.ld_out;
-    for (int c = lane; c < nout; c += 64) {
-        const int l = c / (D * D);
-        const int t = c - l * (D * D);
-        const int a = t / D, b = t - a * D;              // a offsets x, b offsets y (corr.py:133-143)
-        const int4 tx = *(const int4 *)stap[wave][(l * 2 + 0) * D + a];
-        const int4 ty = *(const int4 *)stap[wave][(l * 2 + 1) * D + b];
-        const float wx0 = __int_as_float(tx.z), wx1 = __int_as_float(tx.w);
-        const float wy0 = __int_as_float(ty.z), wy1 = __int_as_float(ty.w);
-        const float *f = sfp[wave][l];
-        const int y0 = ty.x * FW, y1 = ty.y * FW;
-        const float c00 = wy0 * wx0, c01 = wy0 * wx1, c10 = wy1 * wx0, c11 = wy1 * wx1;
-        float v = c00 * f[y0 + tx.x] + c01 * f[y0 + tx.y];
-        v = v + c10 * f[y1 + tx.x];
-        v = v + c11 * f[y1 + tx.y];
-        o[c] = v;
+#pragma unroll
+    for (int l = 0; l < G::L; ++l) {
+        org[l][0] = org[l][1] = 0;
+#pragma unroll
+        for (int r = 0; r < G::NR; ++r) v[l][r] = 0.f;
+        if (l < p.g.levels) {                                // workgroup-uniform
+            const float sc = 1.0f / (float)(1 << l);        // exact power of two: x * sc == x / 2^l
+            const int w = p.g.lw[l], h = p.g.lh[l], tx = p.g.tx[l];
+            const int ox = axis_tap(cq.x * sc, -R, w).i0, oy = axis_tap(cq.y * sc, -R, h).i0;
+            org[l][0] = ox;
+            org[l][1] = oy;
+            // scalar 64-bit base of the workgroup's maps + a 32-bit per-lane byte offset (QB maps < 4 GiB)
+            const char *img = (const char *)(p.pyr + p.g.off[l] + q0 * (int64_t)p.g.map[l]);
+            const unsigned qoff = (unsigned)qc * (unsigned)p.g.map[l];
+#pragma unroll
+            for (int r = 0; r < G::NR; ++r) {
+                const int y = min(oy + (fyx[r] >> 8), h - 1), x = min(ox + (fyx[r] & 255), w - 1);
+                if (RAFT_LOOKUP_ABL & 1)
+                    v[l][r] = cq.x + (float)(y + x);
+                else
+                    v[l][r] = *(const float *)(img + 4u * (qoff + (unsigned)raft_tiled_index(y, x, tx)));
+            }
+        }
     }
 }
 
-// v2 (default): a WORKGROUP handles QB = 7 queries cooperatively, in three phases separated by barriers:
-//   1. axis taps {i0 - origin, i1 - origin, w0, w1} of all QB x levels x 2 x (2r+1) window positions
-//      (one item per thread; the query coordinate is a broadcast load) -> LDS;
-//   2. the (2r+2)^2 footprints: QB x (2r+2)^2 items per level spread over all 256 threads, every load
-//      of every level issued before the first one is consumed (12 independent gathers in flight per
-//      thread instead of 2 dependent rounds per wave), clamped addresses so no load is conditional;
-//   3. the outputs: QB x levels x (2r+1)^2 items, consecutive threads = consecutive channels of a
-//      query (coalesced stores), each from two 16-byte tap reads + four footprint reads in LDS.
-// Index decompositions (channel -> level / window position, footprint slot -> row / column) come from
-// small LDS tables built once per workgroup.  With QB = 7 a 448x512 batch of 4 is 2048 workgroups =
-// exactly the 8 workgroups per CU the chip keeps resident.  (A single-barrier variant with 36 threads
-// per query deriving the origins in registers measured slower: 20.2 vs 18.9 us at B = 4.)
-template <int R, int QB>
-__global__ void __launch_bounds__(256) corr_lookup_wg_kernel(LookupArgs p) {
+// x and y taps of (level l, offset d) relative to the footprint origin, as LDS byte offsets
+template <int R>
+__device__ __forceinline__ void strip_taps(const LookupArgs &p, float2 cq, int l, int d, const int (&org)[4][2],
+                                           int4 &tx, int4 &ty) {
+#pragma clang fp contract(off)
+    using G = StripCfg<R>;
+    const float sc = __int_as_float((127 - l) << 23);       // 2^-l
+    const int w = max(p.g.lw[0] >> l, 1), h = max(p.g.lh[0] >> l, 1);   // floor-halved sizes: size_l = size_0 >> l
+    int ox = org[0][0], oy = org[0][1];
+#pragma unroll
+    for (int k = 1; k < G::L; ++k) {
+        ox = l == k ? org[k][0] : ox;
+        oy = l == k ? org[k][1] : oy;
+    }
+    if (RAFT_LOOKUP_ABL & 8) {
+        tx = make_int4(4 * d, 4 * d + 4, __float_as_int(cq.x), __float_as_int(cq.y));
+        ty = make_int4(4 * G::FW * d, 4 * G::FW * (d + 1), tx.z, tx.w);
+        return;
+    }
+    const AxisTap ax = axis_tap(cq.x * sc, d - R, w), ay = axis_tap(cq.y * sc, d - R, h);
+    tx.x = (ax.i0 - ox) * 4;
+    tx.y = (ax.i1 - ox) * 4;
+    tx.z = __float_as_int(ax.w0);
+    tx.w = __float_as_int(ax.w1);
+    ty.x = (ay.i0 - oy) * (4 * G::FW);
+    ty.y = (ay.i1 - oy) * (4 * G::FW);
+    ty.z = __float_as_int(ay.w0);
+    ty.w = __float_as_int(ay.w1);
+}
+
+// the strip (l, a): channels l*D*D + a*D + b, b = 0 .. D-1  (a offsets x, b offsets y: corr.py:133-143)
+template <int R>
+__device__ __forceinline__ void strip_eval(const float *f, const int (*ty4)[4], int4 tx, float (&o)[StripCfg<R>::D]) {
 #pragma clang fp contract(off)   // keep mul/add unfused: same roundings as the unfused reference ops
-    constexpr int L = RAFT_MAX_LEVELS, D = 2 * R + 1, FW = 2 * R + 2, FP = FW * FW, NT = L * 2 * D;
-    constexpr int NI = (QB * FP + 255) / 256, NOUT = L * D * D;
-    __shared__ float sfp[QB][L][FP];
-    __shared__ __attribute__((aligned(16))) int stap[QB][NT][4];
-    __shared__ int sorg[QB][L][2];
-    __shared__ int sdec[NOUT];     // output channel c -> (x-tap entry, y-tap entry, level) packed 10 + 10 + 4 bits
-    __shared__ int sfpd[FP];       // footprint slot -> (fy << 8) | fx
+    using G = StripCfg<R>;
+    const float wx0 = __int_as_float(tx.z), wx1 = __int_as_float(tx.w);
+    const char *f0 = (const char *)f + tx.x, *f1 = (const char *)f + tx.y;
+    if (RAFT_LOOKUP_ABL & 2) {
+#pragma unroll
+        for (int b = 0; b < G::D; ++b) o[b] = wx0 + (float)b;
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < G::D; ++b) {
+        const int4 ty = *(const int4 *)ty4[b];
+        const float wy0 = __int_as_float(ty.z), wy1 = __int_as_float(ty.w);
+        const float c00 = wy0 * wx0, c01 = wy0 * wx1, c10 = wy1 * wx0, c11 = wy1 * wx1;
+        float t = c00 * *(const float *)(f0 + ty.x) + c01 * *(const float *)(f1 + ty.x);
+        t = t + c10 * *(const float *)(f0 + ty.y);
+        t = t + c11 * *(const float *)(f1 + ty.y);
+        o[b] = t;
+    }
+}
+
+template <int R, int STAGE>
+__global__ void __launch_bounds__(256) corr_lookup_strip_kernel(LookupArgs p) {
+    using G = StripCfg<R>;
+    constexpr int L = G::L, D = G::D, FP = G::FP, SP = G::SP, QB = G::QB, NR = G::NR, NOUT = G::NOUT;
+    static_assert(QB * NOUT <= QB * L * FP, "staged rows alias the footprints");
+    __shared__ __attribute__((aligned(16))) float sfp[QB * L * FP];
+    __shared__ __attribute__((aligned(16))) int sty[QB * SP][4];
     const int tid = threadIdx.x;
+    const int ql = tid / SP, j = tid - ql * SP;
+    const int l = j / D, a = j - l * D;
     const int64_t q0 = (int64_t)blockIdx.x * QB;
     const int nq_here = (int)((p.nq - q0) < QB ? (p.nq - q0) : QB);
-    const int levels = p.g.levels;
+    const bool active = ql < nq_here;
+    if (RAFT_LOOKUP_ABL & 16) return;
+    const bool strip = active && l < p.g.levels;
+    const int qc = active ? ql : nq_here - 1;               // clamp: every load below is unconditional
+    const float2 cq = *(const float2 *)(p.coords + 2 * (q0 + qc));
 
-    // ---- index tables (the divisions by 81 / 9 / 10 are done once per workgroup, not once per item)
-    for (int c = tid; c < NOUT; c += 256) {
-        const int l = c / (D * D), t = c - l * (D * D);
-        const int a = t / D, b = t - a * D;              // a offsets x, b offsets y (corr.py:133-143)
-        sdec[c] = ((l * 2 + 0) * D + a) | (((l * 2 + 1) * D + b) << 10) | (l << 20);
-    }
-    if (tid < FP) sfpd[tid] = ((tid / FW) << 8) | (tid % FW);
-
-    // ---- phase 1: axis taps; entry t = (l*2 + axis)*D + d
-    for (int it = tid; it < QB * NT; it += 256) {
-        const int qi = it / NT, t = it - qi * NT;
-        const int l = t / (2 * D), r = t - l * (2 * D);
-        const int axis = r / D, d = r - axis * D;
-        if (qi < nq_here && l < levels) {
-            const float cq = p.coords[2 * (q0 + qi) + axis];
-            const float sc = 1.0f / (float)(1 << l);   // exact power of two: x * sc == x / 2^l
-            const int size = axis ? p.g.lh[l] : p.g.lw[l];
-            const float c = cq * sc;
-            const AxisTap org = axis_tap(c, -R, size), tp = axis_tap(c, d - R, size);
-            stap[qi][t][0] = tp.i0 - org.i0;
-            stap[qi][t][1] = tp.i1 - org.i0;
-            stap[qi][t][2] = __float_as_int(tp.w0);
-            stap[qi][t][3] = __float_as_int(tp.w1);
-            if (d == 0) sorg[qi][l][axis] = org.i0;
+    float v[L][NR];
+    int org[L][2];
+    strip_gather<R>(p, q0, qc, cq, j, v, org);
+    int4 tx, ty;
+    strip_taps<R>(p, cq, l, a, org, tx, ty);
+    if (active) *(int4 *)sty[tid] = ty;
+#pragma unroll
+    for (int k = 0; k < L; ++k)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int s = j + SP * r;
+            if (s < FP && active) sfp[(ql * L + k) * FP + s] = v[k][r];
         }
-    }
     __syncthreads();
 
-    // ---- phase 2: footprints (all loads first, then the LDS writes)
-    float v[L][NI];
-    int qk[NI], fk[NI];
+    float o[D];
+    if (strip) strip_eval<R>(sfp + (ql * L + l) * FP, sty + ql * SP + l * D, tx, o);
+    if ((RAFT_LOOKUP_ABL & 4) && o[0] != 12345.678f) return;
+    if (STAGE == 0) {
+        if (strip) {
+            float *dst = p.out + (q0 + ql) * (int64_t)p.ld_out + j * D;
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        const int it = tid + 256 * k;
-        int qi = it / FP;
-        fk[k] = sfpd[it - qi * FP];
-        qk[k] = qi < nq_here ? qi : nq_here - 1;          // clamp: the loads are unconditional
-    }
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        if (l < levels) {
-            const int w = p.g.lw[l], h = p.g.lh[l];
-            const float *lvl = p.pyr + p.g.off[l] + q0 * ((int64_t)h * w);
-            const int map = h * w;
-#pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                const int2 o = *(const int2 *)sorg[qk[k]][l];
-                v[l][k] = lvl[qk[k] * map + min(o.y + (fk[k] >> 8), h - 1) * w + min(o.x + (fk[k] & 255), w - 1)];
-            }
+            for (int b = 0; b < D; ++b) dst[b] = o[b];
         }
-    }
+    } else {
+        __syncthreads();                                     // every strip has read its footprints
+        if (strip) {
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        if (l < levels) {
-#pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                const int it = tid + 256 * k;
-                if (it < QB * FP) (&sfp[0][0][0])[(it / FP) * (L * FP) + l * FP + (it % FP)] = v[l][k];
-            }
+            for (int b = 0; b < D; ++b) sfp[ql * NOUT + j * D + b] = o[b];
         }
-    }
-    __syncthreads();
-
-    // ---- phase 3: outputs
-    const int nout = levels * D * D;
-    float *obase = p.out + q0 * (int64_t)p.ld_out;
-    for (int it = tid; it < nq_here * nout; it += 256) {
-        const int qi = it / nout, c = it - qi * nout;
-        const int dec = sdec[c];
-        const int l = dec >> 20;
-        const int4 tx = *(const int4 *)stap[qi][dec & 1023];
-        const int4 ty = *(const int4 *)stap[qi][(dec >> 10) & 1023];
-        const float wx0 = __int_as_float(tx.z), wx1 = __int_as_float(tx.w);
-        const float wy0 = __int_as_float(ty.z), wy1 = __int_as_float(ty.w);
-        const float *f = sfp[qi][l];
-        const int y0 = ty.x * FW, y1 = ty.y * FW;
-        const float c00 = wy0 * wx0, c01 = wy0 * wx1, c10 = wy1 * wx0, c11 = wy1 * wx1;
-        float o = c00 * f[y0 + tx.x] + c01 * f[y0 + tx.y];
-        o = o + c10 * f[y1 + tx.x];
-        o = o + c11 * f[y1 + tx.y];
-        obase[qi * p.ld_out + c] = o;
+        __syncthreads();
+        static_assert(NOUT % 4 == 0, "rows are copied as 16-byte chunks");
+        for (int i = tid; i < nq_here * (NOUT / 4); i += 256) {
+            const int qi = i / (NOUT / 4), c4 = i - qi * (NOUT / 4);
+            *(f32x4 *)(p.out + (q0 + qi) * (int64_t)p.ld_out + 4 * c4) = *(const f32x4 *)(sfp + qi * NOUT + 4 * c4);
+        }
     }
 }
 
 template <int R>
-__global__ void __launch_bounds__(256) corr_lookup_v0_kernel(LookupArgs p) {
-#pragma clang fp contract(off)   // keep mul/add unfused: same roundings as the unfused reference ops
-    constexpr int D = 2 * R + 1, FW = 2 * R + 2, FP = FW * FW;
-    __shared__ float sfp[4][RAFT_MAX_LEVELS][FP];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
-    const bool active = q < p.nq;
-    float cx0 = 0.f, cy0 = 0.f;
-    if (active) {
-        cx0 = p.coords[2 * q];
-        cy0 = p.coords[2 * q + 1];
-    }
-    if (active) {
-#pragma unroll
-        for (int l = 0; l < RAFT_MAX_LEVELS; ++l) {
-            if (l >= p.g.levels) break;
-            const float sc = 1.0f / (float)(1 << l);   // exact power of two: x * sc == x / 2^l
-            const int w = p.g.lw[l], h = p.g.lh[l];
-            const AxisTap tx = axis_tap(cx0 * sc, -R, w);
-            const AxisTap ty = axis_tap(cy0 * sc, -R, h);
-            const float *img = p.pyr + p.g.off[l] + q * ((int64_t)h * w);
-            for (int i = lane; i < FP; i += 64) {
-                const int fy = i / FW, fx = i - fy * FW;
-                const int yy = min(ty.i0 + fy, h - 1), xx = min(tx.i0 + fx, w - 1);
-                sfp[wave][l][i] = img[yy * w + xx];
-            }
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-    const int nout = p.g.levels * D * D;
-    float *o = p.out + q * (int64_t)p.ld_out;
-    for (int c = lane; c < nout; c += 64) {
-        const int l = c / (D * D);
-        const int t = c - l * (D * D);
-        const int a = t / D, b = t - a * D;              // a offsets x, b offsets y (corr.py:133-143)
-        const float sc = 1.0f / (float)(1 << l);
-        const int w = p.g.lw[l], h = p.g.lh[l];
-        const float cx = cx0 * sc, cy = cy0 * sc;
-        const AxisTap ox = axis_tap(cx, -R, w), oy = axis_tap(cy, -R, h);   // footprint origin
-        const AxisTap tx = axis_tap(cx, a - R, w), ty = axis_tap(cy, b - R, h);
-        const float *f = sfp[wave][l];
-        const int x0 = tx.i0 - ox.i0, x1 = tx.i1 - ox.i0;
-        const int y0 = (ty.i0 - oy.i0) * FW, y1 = (ty.i1 - oy.i0) * FW;
-        const float c00 = ty.w0 * tx.w0, c01 = ty.w0 * tx.w1, c10 = ty.w1 * tx.w0, c11 = ty.w1 * tx.w1;
-        float v = c00 * f[y0 + x0] + c01 * f[y0 + x1];
-        v = v + c10 * f[y1 + x0];
-        v = v + c11 * f[y1 + x1];
-        o[c] = v;
-    }
+static void launch_lookup(const LookupArgs &a, bool staged, hipStream_t s) {
+    const int grid = raft_ceil_div(a.nq, StripCfg<R>::QB);
+    const char *e = getenv("RAFT_LOOKUP_LDS_PAD");   // tuning switch: unused dynamic LDS caps the workgroups per CU
+    const int pad = e ? atoi(e) : 0;
+    if (staged)
+        corr_lookup_strip_kernel<R, 1><<<grid, 256, pad, s>>>(a);
+    else
+        corr_lookup_strip_kernel<R, 0><<<grid, 256, pad, s>>>(a);
 }
 
 extern "C" int raft_corr_lookup_f32(const float *pyr, const int64_t *level_offsets, const float *coords, int B,
@@ -535,29 +498,15 @@ extern "C" int raft_corr_lookup_f32(const float *pyr, const int64_t *level_offse
     a.out = out;
     a.nq = (int64_t)B * h * w;
     a.ld_out = ld_out;
-    const int blocks = raft_ceil_div(a.nq, 4);
     hipStream_t s = (hipStream_t)stream;
-    const char *ver = getenv("RAFT_LOOKUP_VERSION");   // A/B timing switch only: 0, 1 = wave-per-query kernels
-    const int version = ver ? atoi(ver) : 2;
-    constexpr int QB = 7;
-    const int wg_blocks = raft_ceil_div(a.nq, QB);
-    if (radius == 4) {
-        if (version == 0)
-            corr_lookup_v0_kernel<4><<<blocks, 256, 0, s>>>(a);
-        else if (version == 1)
-            corr_lookup_kernel<4><<<blocks, 256, 0, s>>>(a);
-        else
-            corr_lookup_wg_kernel<4, QB><<<wg_blocks, 256, 0, s>>>(a);
-    } else if (radius == 3) {
-        if (version == 0)
-            corr_lookup_v0_kernel<3><<<blocks, 256, 0, s>>>(a);
-        else if (version == 1)
-            corr_lookup_kernel<3><<<blocks, 256, 0, s>>>(a);
-        else
-            corr_lookup_wg_kernel<3, QB><<<wg_blocks, 256, 0, s>>>(a);
-    } else {
+    const char *ver = getenv("RAFT_LOOKUP_STAGED");   // A/B timing switch only: 0 = direct strip stores
+    const bool staged = (ver ? atoi(ver) != 0 : true) && levels == 4 && (ld_out & 3) == 0 && raft_aligned16(out);
+    if (radius == 4)
+        launch_lookup<4>(a, staged, s);
+    else if (radius == 3)
+        launch_lookup<3>(a, staged, s);
+    else
         return RAFT_E_UNSUPPORTED;
-    }
     return raft_launch_status();
 }
 

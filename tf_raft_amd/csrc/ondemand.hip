@@ -16,7 +16,7 @@ struct OnDemandArgs {
     const float *coords;     // (B*N, 2)
     float *out;
     int64_t row_off[RAFT_MAX_LEVELS];   // first row of each level inside T
-    int lh[RAFT_MAX_LEVELS], lw[RAFT_MAX_LEVELS];
+    int lh[RAFT_MAX_LEVELS], lw[RAFT_MAX_LEVELS], tx[RAFT_MAX_LEVELS];
     int64_t nq;
     int N, T, levels, ld_out;
     float sqrt_c;
@@ -44,14 +44,14 @@ __global__ void __launch_bounds__(256) corr_lookup_ondemand_kernel(OnDemandArgs 
         const float *f2b = p.f2pyr + b * (int64_t)p.T * C;
         for (int l = 0; l < p.levels; ++l) {
             const float sc = 1.0f / (float)(1 << l);
-            const int w = p.lw[l], h = p.lh[l];
+            const int w = p.lw[l], h = p.lh[l], tiles_x = p.tx[l];
             const AxisTap tx = axis_tap(cx0 * sc, -R, w);
             const AxisTap ty = axis_tap(cy0 * sc, -R, h);
             const float *lvl = f2b + p.row_off[l] * C + lane * V;
             for (int i = 0; i < FP; ++i) {
                 const int fy = i / FW, fx = i - fy * FW;
                 const int yy = min(ty.i0 + fy, h - 1), xx = min(tx.i0 + fx, w - 1);
-                const float *row = lvl + ((int64_t)yy * w + xx) * C;
+                const float *row = lvl + (int64_t)raft_tiled_index(yy, xx, tiles_x) * C;   // rows in tile order
                 float s = 0.f;
 #pragma unroll
                 for (int v = 0; v < V; ++v) s = fmaf(f1[v], row[v], s);
@@ -112,14 +112,15 @@ extern "C" int raft_corr_lookup_ondemand_f32(const float *fmap1, const float *fm
     int64_t t = 0;
     int ch = h, cw = w;
     for (int l = 0; l < RAFT_MAX_LEVELS; ++l) {
-        a.row_off[l] = 0; a.lh[l] = 1; a.lw[l] = 1;
+        a.row_off[l] = 0; a.lh[l] = 1; a.lw[l] = 1; a.tx[l] = 1;
     }
     for (int l = 0; l < levels; ++l) {
         RAFT_REQUIRE(ch >= 1 && cw >= 1, RAFT_E_SHAPE);
         a.row_off[l] = t;
         a.lh[l] = ch;
         a.lw[l] = cw;
-        t += (int64_t)ch * cw;
+        a.tx[l] = raft_tiles_x(cw);
+        t += raft_map_floats(ch, cw);
         ch /= 2;
         cw /= 2;
     }

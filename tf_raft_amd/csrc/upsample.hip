@@ -97,3 +97,22 @@ extern "C" int raft_upflow8_f32(const float *flow, int B, int h, int w, float *o
                                                                                (float2 *)out);
     return raft_launch_status();
 }
+
+// Streaming copy used by bench.py to measure the box's HBM copy bandwidth (read + write, 16 bytes per lane, one
+// element per thread: the flat grid measured 6.0-6.1 TB/s on MI355X, a grid-stride loop 4.7-5.4, hipMemcpyAsync
+// 4.8-5.3 -- tools/ablate/copy_bw.hip).
+__global__ void __launch_bounds__(256) stream_copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
+                                                          int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
+}
+
+extern "C" int raft_stream_copy_f32(const float *src, float *dst, int64_t n, void *stream) {
+    RAFT_REQUIRE_PTR(src);
+    RAFT_REQUIRE_PTR(dst);
+    RAFT_REQUIRE(n > 0 && n % 4 == 0 && n / 1024 < 0x7fffffff, RAFT_E_SHAPE);
+    RAFT_REQUIRE(raft_aligned16(src) && raft_aligned16(dst), RAFT_E_ALIGN);
+    const int64_t n4 = n / 4;
+    stream_copy_kernel<<<raft_ceil_div(n4, 256), 256, 0, (hipStream_t)stream>>>((const f32x4 *)src, (f32x4 *)dst, n4);
+    return raft_launch_status();
+}

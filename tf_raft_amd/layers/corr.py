@@ -22,6 +22,27 @@ def _geometry(B, h, w, levels):
     return off, list(lh), list(lw)
 
 
+def _tiles(h, w):
+    return (h + 3) // 4, (w + 7) // 8
+
+
+def tile_maps(maps):
+    """(n, h, w) row-major maps -> (n, map_floats) in the library's 4x8-tiled, zero-padded map layout
+    (include/raft_hip.h, raft_corr_pyramid_layout)."""
+    n, h, w = maps.shape
+    ty, tx = _tiles(h, w)
+    padded = torch.zeros((n, ty * 4, tx * 8), device=maps.device, dtype=maps.dtype)
+    padded[:, :h, :w] = maps
+    return padded.view(n, ty, 4, tx, 8).permute(0, 1, 3, 2, 4).reshape(n, ty * tx * 32)
+
+
+def untile_maps(flat, h, w):
+    """Inverse of ``tile_maps``: (n, map_floats) -> (n, h, w)."""
+    n = flat.shape[0]
+    ty, tx = _tiles(h, w)
+    return flat.view(n, ty, tx, 4, 8).permute(0, 1, 3, 2, 4).reshape(n, ty * 4, tx * 8)[:, :h, :w]
+
+
 def bilinear_sampler(image, coords):
     """reference corr.py:28-69.  image (N, h, w, 1); coords (N, kh, kw, 2) xy -> (N, kh, kw, 1).
     Clamp, then ceil/floor weights: an integer or out-of-range coordinate samples 0."""
@@ -65,8 +86,8 @@ class CorrBlock:
     """reference corr.py:99-162.
 
     ``CorrBlock(fmap1, fmap2, num_levels, radius)`` builds the all-pairs correlation volume and
-    its pyramid on the device; ``corr_pyramid`` is the list of ``(bs*h*w, h_l, w_l, 1)`` maps
-    (views into one allocation); ``retrieve(coords)`` returns ``(bs, h, w, levels*(2r+1)^2)``.
+    its pyramid on the device (one allocation, per-query maps 4x8-tiled); ``corr_pyramid`` is the list
+    of ``(bs*h*w, h_l, w_l, 1)`` maps (un-tiled copies); ``retrieve(coords)`` returns ``(bs, h, w, levels*(2r+1)^2)``.
 
     ``alternate=True`` stores no volume: ``retrieve`` computes the footprint correlations on
     demand from ``fmap1`` and the pooled ``fmap2`` pyramid (high-resolution inputs).
@@ -106,10 +127,15 @@ class CorrBlock:
         bs, h, w, _ = self.fmap1.shape
         n = bs * h * w
         out = []
-        for l in range(self.num_levels):
-            cnt = n * self._lh[l] * self._lw[l]
-            out.append(_dev.wrap(self._pyr[self._off[l]:self._off[l] + cnt].view(n, self._lh[l], self._lw[l], 1)))
+        for l in range(self.num_levels):       # un-tiled copies in the reference's (bs*h*w, h_l, w_l, 1) shape
+            flat = self._pyr[self._off[l]:self._off[l + 1]].view(n, -1)
+            out.append(_dev.wrap(untile_maps(flat, self._lh[l], self._lw[l]).contiguous().unsqueeze(-1)))
         return out
+
+    def _set_level(self, l, maps):
+        """Overwrite level ``l`` of the stored volume with (bs*h*w, h_l, w_l[, 1]) maps (parity tests)."""
+        maps = _dev.to_device(maps).reshape(-1, self._lh[l], self._lw[l])
+        self._pyr[self._off[l]:self._off[l + 1]].copy_(tile_maps(maps).reshape(-1))
 
     def retrieve(self, coords, out=None, ld_out=None):
         """reference corr.py:116-152.  coords: (bs, h, w, 2) xy.  ``out``/``ld_out`` let the

@@ -61,7 +61,7 @@ def main():
         ver = sys.argv[2]
         B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
         reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-        os.environ['RAFT_LOOKUP_VERSION'] = ver.lstrip('v')
+        os.environ["RAFT_LOOKUP_STAGED"] = "0" if ver in ("v3", "direct") else "1"
         from tf_raft_amd.layers.corr import CorrBlock
         f1 = rng.normal(size=(B, H, W, 256)).astype(np.float32)
         f2 = rng.normal(size=(B, H, W, 256)).astype(np.float32)
