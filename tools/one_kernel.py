@@ -1,7 +1,8 @@
 """Run ONE kernel configuration repeatedly (for rocprofv3 --pmc passes and A/B timing on the GPU box).
 
   python tools/one_kernel.py conv <layer> <tile|auto> [B] [reps]
-  python tools/one_kernel.py lookup <v0|v1> [B] [reps]
+  python tools/one_kernel.py lookup <direct|staged> [B] [reps]
+  python tools/one_kernel.py upsample [B] [reps]
 Prints the HIP-event average per launch.
 """
 import os
@@ -76,6 +77,18 @@ def main():
         ms = timed(run, reps)
         bytes_ = B * H * W * (4 * 100 * 4 + 8 + 324 * 4)
         print(f'lookup {ver} B={B}: {ms*1e3:.1f} us  {bytes_ / ms / 1e6:.0f} GB/s algorithmic')
+    elif kind == 'upsample':
+        B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+        reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+        flow = _dev.to_device(rng.normal(size=(B, H, W, 2)).astype(np.float32))
+        mask = _dev.to_device(rng.normal(size=(B, H, W, 576)).astype(np.float32))
+        out = torch.empty((B, 8 * H, 8 * W, 2), device=flow.device)
+
+        def run():
+            check(lib.raft_upsample_convex_f32(_dev.ptr(flow), _dev.ptr(mask), B, H, W, _dev.ptr(out), _dev.stream_ptr()))
+        ms = timed(run, reps)
+        bytes_ = B * H * W * (576 * 4 + 8 + 64 * 2 * 4)
+        print(f'upsample_convex B={B}: {ms*1e3:.1f} us  {bytes_ / ms / 1e6:.0f} GB/s algorithmic')
     else:
         raise SystemExit(__doc__)
 
