@@ -190,10 +190,11 @@ def test_corr_lookup_ondemand_matches_volume(rng, radius, C):
         alt.corr_pyramid
 
 
-def test_upsample_convex_matches_oracle(rng):
+@pytest.mark.parametrize('shape', [(2, 7, 9), (1, 6, 8), (3, 2, 1)])   # odd width: the last pixel pair is half empty
+def test_upsample_convex_matches_oracle(rng, shape):
     from oracle.model import upsample_flow
     from tf_raft_amd import RAFT
-    B, h, w = 2, 7, 9
+    B, h, w = shape
     flow = rng.normal(scale=5.0, size=(B, h, w, 2)).astype(np.float32)
     mask = rng.normal(scale=2.0, size=(B, h, w, 576)).astype(np.float32)
     want = upsample_flow(_t(flow), _t(mask)).numpy()

@@ -3,57 +3,88 @@
 //   raft_upflow8_f32         : upflow8             [reference corr.py:93-96]
 #include "common.h"
 
-// One wavefront per coarse pixel: lane = i*8 + j (sub-row i, sub-col j).  The pixel's 576 mask
-// logits are read with coalesced loads into LDS, then lane (i,j) reads its 9 taps at stride 9
-// (odd stride => conflict-free ds_read_b32), does the softmax in registers, and blends the 3x3
-// zero-padded neighbourhood of 8*flow (wave-uniform => scalar loads).
+// One wavefront per PAIR of x-adjacent coarse pixels.  lane = il*16 + px*8 + j (il = 0..3, px = which pixel of
+// the pair, j = sub-column); the lane produces sub-rows i = il and il + 4, so every store instruction writes four
+// output rows of 16 consecutive float2 = whole 128-byte lines.  The pair's 2 x 576 mask logits are contiguous in
+// memory: 16-byte coalesced loads into LDS (pixel stride 592 floats => the stride-9 tap reads of a half-wave hit 32
+// distinct banks), the 3x4 zero-padded neighbourhood of 8*flow goes to LDS once per pair (broadcast reads), the
+// softmax over the 9 taps runs in registers.  exp(x - max) is evaluated as exp2((x - max) * log2 e) on the
+// transcendental unit and the weights are scaled by one reciprocal of their sum: both within a few ulp of the
+// reference's softmax, far inside the 1e-5 relative tolerance of the parity test.
+constexpr int UPS_PX_STRIDE = 592;
+
 __global__ void __launch_bounds__(256) upsample_convex_kernel(const float *__restrict__ flow,
                                                               const float *__restrict__ mask, int B, int h, int w,
                                                               float *__restrict__ out) {
-    __shared__ float sm[4][576];
+    __shared__ __attribute__((aligned(16))) float sm[4][2 * UPS_PX_STRIDE];
+    __shared__ float2 sf[4][12];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t npix = (int64_t)B * h * w;
-    const int64_t pix = (int64_t)blockIdx.x * 4 + wave;
-    const bool active = pix < npix;
+    const int wp = (w + 1) >> 1;
+    const int64_t npair = (int64_t)B * h * wp;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
+    const bool active = pair < npair;                         // wave-uniform
+    int x0 = 0, y = 0;
+    int64_t b = 0;
+    bool two = false;
     if (active) {
-        const float *m = mask + pix * 576;
+        x0 = 2 * (int)(pair % wp);
+        y = (int)((pair / wp) % h);
+        b = pair / ((int64_t)wp * h);
+        two = x0 + 1 < w;
+        const f32x4 *m = (const f32x4 *)(mask + ((b * h + y) * (int64_t)w + x0) * 576);
+        const int lim = two ? 288 : 144;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) sm[wave][lane + 64 * k] = m[lane + 64 * k];
+        for (int k = 0; k < 5; ++k) {
+            const int f = lane + 64 * k;
+            if (f < lim) {
+                const int px = f >= 144, r = f - 144 * px;
+                *(f32x4 *)(&sm[wave][px * UPS_PX_STRIDE + 4 * r]) = m[f];
+            }
+        }
+        if (lane < 12) {                                      // neighbourhood rows y-1..y+1, columns x0-1..x0+2
+            const int yy = y + lane / 4 - 1, xx = x0 + (lane & 3) - 1;
+            float2 f = make_float2(0.f, 0.f);
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+                f = *(const float2 *)(flow + ((b * h + yy) * (int64_t)w + xx) * 2);
+                f.x *= 8.f;
+                f.y *= 8.f;
+            }
+            sf[wave][lane] = f;
+        }
     }
     __syncthreads();
-    if (!active) return;
-    const int x = (int)(pix % w), y = (int)((pix / w) % h);
-    const int64_t b = pix / ((int64_t)w * h);
-
-    float v[9], mx = -INFINITY;
+    const int il = lane >> 4, px = (lane >> 3) & 1, j = lane & 7;
+    if (!active || (px && !two)) return;
+    float2 nb[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        v[k] = sm[wave][lane * 9 + k];
-        mx = fmaxf(mx, v[k]);
-    }
-    float s = 0.f;
+    for (int k = 0; k < 9; ++k) nb[k] = sf[wave][(k / 3) * 4 + (k % 3) + px];   // patch depth order (ky, kx, ch)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        v[k] = expf(v[k] - mx);
-        s += v[k];
-    }
-    float ox = 0.f, oy = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int i = il + 4 * pass;
+        const float *t = &sm[wave][px * UPS_PX_STRIDE + (i * 8 + j) * 9];
+        float v[9], mx = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;   // patch depth order (ky, kx, ch)
-        float fx = 0.f, fy = 0.f;
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-            const float *f = flow + ((b * h + yy) * (int64_t)w + xx) * 2;
-            fx = 8.f * f[0];
-            fy = 8.f * f[1];
+        for (int k = 0; k < 9; ++k) {
+            v[k] = t[k];
+            mx = fmaxf(mx, v[k]);
         }
-        const float wk = v[k] / s;
-        ox += wk * fx;
-        oy += wk * fy;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            v[k] = __builtin_amdgcn_exp2f((v[k] - mx) * 1.44269504088896341f);
+            s += v[k];
+        }
+        const float inv = 1.0f / s;
+        float ox = 0.f, oy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float wk = v[k] * inv;
+            ox += wk * nb[k].x;
+            oy += wk * nb[k].y;
+        }
+        float2 *o = (float2 *)out + (b * (8 * h) + (8 * y + i)) * (int64_t)(8 * w) + (8 * (x0 + px) + j);
+        *o = make_float2(ox, oy);
     }
-    const int i = lane >> 3, j = lane & 7;
-    float2 *o = (float2 *)out + (b * (8 * h) + (8 * y + i)) * (int64_t)(8 * w) + (8 * x + j);
-    *o = make_float2(ox, oy);
 }
 
 extern "C" int raft_upsample_convex_f32(const float *flow, const float *mask, int B, int h, int w, float *out,
@@ -62,8 +93,9 @@ extern "C" int raft_upsample_convex_f32(const float *flow, const float *mask, in
     RAFT_REQUIRE_PTR(mask);
     RAFT_REQUIRE_PTR(out);
     RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
-    const int64_t npix = (int64_t)B * h * w;
-    upsample_convex_kernel<<<raft_ceil_div(npix, 4), 256, 0, (hipStream_t)stream>>>(flow, mask, B, h, w, out);
+    RAFT_REQUIRE(raft_aligned16(mask), RAFT_E_ALIGN);
+    const int64_t npair = (int64_t)B * h * ((w + 1) / 2);
+    upsample_convex_kernel<<<raft_ceil_div(npair, 4), 256, 0, (hipStream_t)stream>>>(flow, mask, B, h, w, out);
     return raft_launch_status();
 }
 
