@@ -41,6 +41,11 @@ int raft_version(void);
 /* Human-readable message for a return code (RAFT_E_* or hipError_t). */
 const char *raft_error_string(int rc);
 
+/* CRC-32C (Castagnoli, reflected 0x1EDC6F41) of `n` bytes, continuing from `crc` (0 to start).
+ * Host-only.  The checksum of the TensorFlow tensor-bundle checkpoint files the reference
+ * stores its weights in (README.md:66-96); used by tf_raft_amd/checkpoint.py. */
+uint32_t raft_crc32c(uint32_t crc, const void *data, size_t n);
+
 /* ------------------------------------------------------------------ correlation volume */
 
 /* Pyramid geometry.  Level l holds, for each of the B*h*w query pixels, an (lh[l], lw[l]) map;

@@ -100,6 +100,30 @@ def test_shim_import_path_and_bad_inputs():
         RAFT(weights={'fnet/conv1/kernel': np.zeros((7, 7, 3, 64), np.float32)})
 
 
+@pytest.mark.parametrize('variant', ['raft', 'small'])
+def test_tf_checkpoint_round_trip_through_the_model(tmp_path, variant):
+    """reference README.md:66-96: save_weights / load_weights on a TensorFlow checkpoint prefix -> same predictions."""
+    import tf_raft_amd
+    from tf_raft_amd import weights as wm
+    cls = tf_raft_amd.RAFT if variant == 'raft' else tf_raft_amd.SmallRAFT
+    trained = cls(weights=wm.init_weights(variant, seed=11, perturb=True), iters_pred=3)
+    prefix = str(tmp_path / 'checkpoints' / 'model')
+    trained.save_weights(prefix)
+    assert os.path.exists(prefix + '.index') and os.path.exists(prefix + '.data-00000-of-00001')
+    fresh = cls(iters_pred=3)                                   # Keras-default weights, then restore
+    i1, i2 = _images(3, 1, 64, 96)
+    before = fresh([i1, i2])[-1].numpy()
+    fresh.load_weights(prefix)
+    want = trained([i1, i2])[-1].numpy()
+    got = fresh([i1, i2])[-1].numpy()
+    assert np.abs(before - want).max() > 1e-3                    # the restore changed something
+    np.testing.assert_array_equal(got, want)
+    trained.save_weights(str(tmp_path / 'w.npz'))
+    fresh2 = cls(iters_pred=3)
+    fresh2.load_weights(str(tmp_path / 'w.npz'))
+    np.testing.assert_array_equal(fresh2([i1, i2])[-1].numpy(), want)
+
+
 # ------------------------------------------------------------------ encoders
 @pytest.mark.parametrize('variant,H,W', [('raft', 128, 160), ('small', 96, 128)])
 def test_encoders_match_oracle(variant, H, W):

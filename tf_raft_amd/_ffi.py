@@ -52,6 +52,7 @@ _I = C.c_int
 _SIGNATURES = {
     'raft_version': (C.c_int, []),
     'raft_error_string': (C.c_char_p, [_I]),
+    'raft_crc32c': (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     'raft_corr_pyramid_layout': (_I, [_I, _I, _I, _I, c_i64_p, c_int_p, c_int_p]),
     'raft_corr_build_workspace_floats': (C.c_int64, [_I, _I, _I, _I, _I]),
     'raft_corr_build_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, c_i64_p, _P, _P]),

@@ -15,7 +15,8 @@ Execution: encoders on PyTorch-ROCm, then everything on hand-written HIP kernels
 the current HIP stream with no host synchronisation.  There is no CPU fallback.
 
 Out of scope (training plumbing of the reference, model.py:111-170): ``compile``, ``train_step``,
-``test_step``, ``reset_metrics``.  ``predict_step`` is provided.
+``test_step``, ``reset_metrics``.  ``predict_step``, ``load_weights`` / ``save_weights`` (TensorFlow
+tensor-bundle checkpoints, read and written without TensorFlow) are provided.
 """
 from __future__ import annotations
 
@@ -60,6 +61,7 @@ class RAFT:
         if weights is None:
             weights = weights_mod.init_weights(self.variant, seed)     # Keras default initialisers
         weights_mod.check_weights(self.variant, weights)
+        self._weights = dict(weights)
         self._build(weights)
 
     def _build(self, weights):
@@ -72,14 +74,33 @@ class RAFT:
     # ---- weights ------------------------------------------------------------------------------
     def set_weights(self, weights: Dict[str, np.ndarray]) -> None:
         weights_mod.check_weights(self.variant, weights)
+        self._weights = dict(weights)
         self.fnet.set_weights(weights)
         self.cnet.set_weights(weights)
         self.update_block.set_weights(weights)
 
     def load_weights(self, path: str) -> None:
-        """Load a ``.npz`` written by ``tf_raft_amd.weights.save_weights`` (Keras layout).  The
-        reference's TF checkpoint format (README.md:66-96) needs a tensor-bundle reader: not built."""
-        self.set_weights(weights_mod.load_weights(path))
+        """reference README.md:66-96 / train_sintel.py:117-123: ``model.load_weights('checkpoints/model')``.
+        ``path`` is a TensorFlow checkpoint prefix (``<path>.index`` + ``<path>.data-*``, read without TensorFlow by
+        ``tf_raft_amd.checkpoint``) or a ``.npz`` written by ``save_weights`` (Keras layout either way)."""
+        from . import checkpoint
+        if checkpoint.is_tf_checkpoint(path):
+            self.set_weights(checkpoint.load_tf_checkpoint(path, self.variant))
+        else:
+            self.set_weights(weights_mod.load_weights(path))
+
+    def get_weights_dict(self) -> Dict[str, np.ndarray]:
+        """The current weights in Keras layout under ``tf_raft_amd.weights`` names."""
+        return dict(self._weights)
+
+    def save_weights(self, path: str) -> None:
+        """reference train_sintel.py:104-107 (ModelCheckpoint(save_weights_only=True)): ``path`` ending in ``.npz``
+        writes the NumPy container, anything else a TensorFlow tensor-bundle checkpoint prefix."""
+        from . import checkpoint
+        if path.endswith('.npz'):
+            weights_mod.save_weights(path, self._weights)
+        else:
+            checkpoint.write_tf_checkpoint(path, self._weights, self.variant)
 
     # ---- reference helpers ----------------------------------------------------------------------
     def initialize_flow(self, image):
