@@ -98,7 +98,7 @@ static int pick_code(const ConvArgs &a, int kh, int kw) {
             if (resident > reg_limit) resident = reg_limit;
             const int64_t conc = per_cu < resident ? per_cu : resident;
             const double pen = conc >= 3 ? 1.0 : (conc == 2 ? 1.05 : 1.15);
-            const double eff = th == 4 ? 0.88 : 1.0;   // short tiles: more halo and weight traffic per MFMA (measured)
+            const double eff = (th == 4 && kh * kw > 1) ? 0.88 : 1.0;   // short tiles: more halo traffic per MFMA (measured; a 1x1 kernel has no halo)
             const double cost = (double)per_cu * th * 16 * 64 * tn * pen / eff;
             if (cost < best) {
                 best = cost;

@@ -28,6 +28,9 @@
 //     block would serialise them.
 // Accumulation order: chunk-major, tap-minor, k ascending within the lane-group permutation.
 #pragma once
+#include <stdlib.h>
+#include <type_traits>
+
 #include "conv_mfma.h"
 
 // Template parameters beyond the tile shape:
@@ -38,7 +41,10 @@
 //   STATS          also write per-tile (sum, sum of squares) of the raw output per channel (instance-norm moments)
 //   STEM           7x7 stride-2 stem on a 4-channel-padded image: K chunk c = kernel row c, k = (kx, ch) of the
 //                  7 x 4 input window (+ 4 zero columns); KH = KW = 1 and cin = 7 * 32 in this mode
-template <int KH, int KW, int TH, int TN, int EPI, int STRIDE = 1, int PRE = 0, int STATS = 0, int STEM = 0>
+//   DEEP           weight (B) fragments are fetched TWO rounds ahead through a 4-slot register ring instead of one
+//                  round ahead: a layer that leaves one workgroup per CU (N = 128 at B = 4: one wave per SIMD, nothing
+//                  to switch to) otherwise waits out part of every L2 round trip -- a round is only TH x 32 MFMA cycles
+template <int KH, int KW, int TH, int TN, int EPI, int STRIDE = 1, int PRE = 0, int STATS = 0, int STEM = 0, int DEEP = 0>
 __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
     constexpr int TW = 16, NKK = 2;
     constexpr int TAPS = KH * KW, R = TAPS * NKK;
@@ -144,7 +150,7 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
     };
 
     // ---- fragment fetch
-    f32x4 fa[2][TH], fb[2][TN];
+    f32x4 fa[2][TH], fb[DEEP ? 4 : 2][TN];
     const int a_lane = LR * FSTEP * LDA + G * 4;                          // + window shift + kk*16
     const unsigned b_lane = (unsigned)(((G * p.npad) + n0 + wn * 16 * TN + LR) * 16);   // bytes
     auto frag_a = [&](int buf, int q, f32x4 *a) {
@@ -193,6 +199,49 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
     __syncthreads();
     if (nch > 1) gload(1);
     frag_a(0, 0, fa[0]);
+    if constexpr (DEEP) {
+        // global round g = c * R + q uses ring slot g & 3 (R is even, so two chunks advance the ring by a multiple of
+        // 4: the slot of every round is a compile-time constant of (chunk parity, q))
+        static_assert(R % 2 == 0 && R >= 2, "ring indexing needs an even number of rounds per chunk");
+        frag_b(0, 1, fb[1]);
+        auto chunk = [&](auto parity, int c) {
+            constexpr int P = decltype(parity)::value;
+            const bool more = c + 1 < nch;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int cur = q & 1;
+                constexpr int RB = P * R;
+                if (q + 1 < R)
+                    frag_a(P, q + 1, fa[cur ^ 1]);
+                else if (more)
+                    frag_a(P ^ 1, 0, fa[cur ^ 1]);
+                if (q + 2 < R)
+                    frag_b(c, q + 2, fb[(RB + q + 2) & 3]);
+                else if (more)
+                    frag_b(c + 1, q + 2 - R, fb[(RB + q + 2) & 3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < TH; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i][r], fb[(RB + q) & 3][j][r], acc[i][j], 0, 0, 0);
+                if (q == R - 2) {
+                    if (more) {
+                        lstore(P ^ 1);
+                        if (c + 2 < nch) gload(c + 2);
+                    }
+                    __syncthreads();
+                }
+            }
+        };
+        int c = 0;
+        for (; c + 1 < nch; c += 2) {
+            chunk(std::integral_constant<int, 0>{}, c);
+            chunk(std::integral_constant<int, 1>{}, c + 1);
+        }
+        if (c < nch) chunk(std::integral_constant<int, 0>{}, c);
+    } else
     for (int c = 0; c < nch; ++c) {
         const int buf = c & 1;
         const bool more = c + 1 < nch;
@@ -311,7 +360,7 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float q = tanhf(acc[i][j][r] + bias);
+                    const float q = raft_tanh(acc[i][j][r] + bias);
                     bstore((1.0f - zv[r]) * hv[r] + zv[r] * q, ro0,
                            (nok & mok[r]) ? (mrow[r] * p.ldo0 + n) * 4u : RAFT_OOB);
                 }
@@ -339,12 +388,22 @@ int raft_launch_conv_halo_3x3(const ConvArgs &a, int th, int tn, int epi, hipStr
 int raft_launch_conv_halo_1x5(const ConvArgs &a, int th, int tn, int epi, hipStream_t s);
 int raft_launch_conv_halo_5x1(const ConvArgs &a, int th, int tn, int epi, hipStream_t s);
 
+// Deep weight prefetch (DEEP = 1) for the single-column-block tiles: measured +2..4 % on every update-block layer at
+// B = 4 (profiles/r03j_conv_bench_deep*.txt), same register occupancy.  RAFT_CONV_DEEP = 0 switches it off (A/B timing).
+static inline bool raft_conv_deep(const ConvArgs &, int, int tn, int) {
+    static const int mode = [] { const char *e = getenv("RAFT_CONV_DEEP"); return e ? atoi(e) : 1; }();
+    return tn == 1 && mode != 0;
+}
+
 template <int KH, int KW, int EPI>
 static int raft_launch_conv_halo_tile(const ConvArgs &a, int th, int tn, hipStream_t s) {
     const int tiles = a.B * ((a.H + th - 1) / th) * ((a.W + 15) / 16);
     const int grid = tiles * (a.npad / (64 * tn));
-    const int key = th * 10 + tn;
+    const int key = th * 10 + tn + (raft_conv_deep(a, th, tn, grid) ? 100 : 0);
     switch (key) {
+        case 141: conv_halo_kernel<KH, KW, 4, 1, EPI, 1, 0, 0, 0, 1><<<grid, 256, 0, s>>>(a); break;
+        case 171: conv_halo_kernel<KH, KW, 7, 1, EPI, 1, 0, 0, 0, 1><<<grid, 256, 0, s>>>(a); break;
+        case 181: conv_halo_kernel<KH, KW, 8, 1, EPI, 1, 0, 0, 0, 1><<<grid, 256, 0, s>>>(a); break;
         case 41: conv_halo_kernel<KH, KW, 4, 1, EPI><<<grid, 256, 0, s>>>(a); break;
         case 42: conv_halo_kernel<KH, KW, 4, 2, EPI><<<grid, 256, 0, s>>>(a); break;
         case 71: conv_halo_kernel<KH, KW, 7, 1, EPI><<<grid, 256, 0, s>>>(a); break;
