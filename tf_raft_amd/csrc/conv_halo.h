@@ -173,6 +173,50 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- epilogue resources (set up here so that the epilogue inputs can be prefetched)
+    const int w0 = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;          // valid columns of o0
+    const int w1 = (EPI == EPI_GRU_ZR) ? p.nvalid - p.hid : 0;      // valid columns of o1
+    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + w0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(w1 > 0 ? p.o1 : p.o0), 0, w1 > 0 ? (int)((((long)M - 1) * p.ldo1 + w1) * 4) : 0, 0x00020000);
+    const bool has_e0 = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q || EPI == EPI_RES, has_e1 = EPI == EPI_GRU_Q;
+    const int we = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;
+    const __amdgpu_buffer_rsrc_t re0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_e0 ? (const void *)p.e0 : (const void *)p.o0), 0,
+        has_e0 ? (int)((((long)M - 1) * p.lde0 + we) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t re1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_e1 ? (const void *)p.e1 : (const void *)p.o0), 0,
+        has_e1 ? (int)((((long)M - 1) * p.lde1 + we) * 4) : 0, 0x00020000);
+    auto bstore = [](float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+    };
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+    };
+    // gate / residual inputs of the epilogue are fetched BEFORE the K loop (a layer that leaves one workgroup per CU
+    // has nothing to hide their latency behind afterwards); masked pixels / channels read through RAFT_OOB -> 0
+    float pe0[TH][TN][4], pe1[TH][TN][4];
+    if (EPI == EPI_RES || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
+#pragma unroll
+        for (int i = 0; i < TH; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 16 + LR;
+                const bool nok = n < p.nvalid;
+                const bool isz = n < p.hid;
+                const unsigned ne = (EPI == EPI_GRU_ZR) ? (unsigned)(isz ? n : n - p.hid) : (unsigned)n;
+                const bool want0 = (EPI == EPI_GRU_ZR) ? (nok & !isz) : nok;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int yy = y0 + i, xx = x0 + 4 * G + r;
+                    const bool mokr = (yy < p.H) & (xx < p.W);
+                    const unsigned m = (unsigned)((b * p.H + yy) * p.W + xx);
+                    pe0[i][j][r] = bload(re0, (want0 & mokr) ? (m * p.lde0 + ne) * 4u : RAFT_OOB);
+                    if (EPI == EPI_GRU_Q) pe1[i][j][r] = bload(re1, (nok & mokr) ? (m * p.lde1 + n) * 4u : RAFT_OOB);
+                }
+            }
+    }
     gload(0);
     frag_b(0, 0, fb[0]);
     if (p.init) {
@@ -273,26 +317,6 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
     }
 
     // ---- epilogue: lane owns channel n; accumulator (i, j)[r] is pixel (y0 + i, x0 + 4G + r)
-    const int w0 = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;          // valid columns of o0
-    const int w1 = (EPI == EPI_GRU_ZR) ? p.nvalid - p.hid : 0;      // valid columns of o1
-    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + w0) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(w1 > 0 ? p.o1 : p.o0), 0, w1 > 0 ? (int)((((long)M - 1) * p.ldo1 + w1) * 4) : 0, 0x00020000);
-    const bool has_e0 = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q || EPI == EPI_RES, has_e1 = EPI == EPI_GRU_Q;
-    const int we = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;
-    const __amdgpu_buffer_rsrc_t re0 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(has_e0 ? (const void *)p.e0 : (const void *)p.o0), 0,
-        has_e0 ? (int)((((long)M - 1) * p.lde0 + we) * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t re1 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(has_e1 ? (const void *)p.e1 : (const void *)p.o0), 0,
-        has_e1 ? (int)((((long)M - 1) * p.lde1 + we) * 4) : 0, 0x00020000);
-    auto bstore = [](float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
-    };
-    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
-    };
     float biasv[TN], s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -328,40 +352,25 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
                     bstore(v, ro0, (nok & mok[r]) ? (mrow[r] * p.ldo0 + n) * 4u : RAFT_OOB);
                 }
             } else if (EPI == EPI_RES) {
-                float xv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    xv[r] = bload(re0, (nok & mok[r]) ? (mrow[r] * p.lde0 + n) * 4u : RAFT_OOB);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    bstore(fmaxf(xv[r] + fmaxf(acc[i][j][r] + bias, 0.f), 0.f), ro0,
+                    bstore(fmaxf(pe0[i][j][r] + fmaxf(acc[i][j][r] + bias, 0.f), 0.f), ro0,
                            (nok & mok[r]) ? (mrow[r] * p.ldo0 + n) * 4u : RAFT_OOB);
             } else if (EPI == EPI_GRU_ZR) {
                 const bool isz = n < p.hid;
                 const unsigned nh = (unsigned)(isz ? n : n - p.hid);
-                float hv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    hv[r] = bload(re0, (nok & mok[r] & !isz) ? (mrow[r] * p.lde0 + nh) * 4u : RAFT_OOB);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float g = raft_sigmoid(acc[i][j][r] + bias);
                     const bool ok = nok & mok[r];
                     bstore(g, ro0, (ok & isz) ? (mrow[r] * p.ldo0 + nh) * 4u : RAFT_OOB);
-                    bstore(g * hv[r], ro1, (ok & !isz) ? (mrow[r] * p.ldo1 + nh) * 4u : RAFT_OOB);
+                    bstore(g * pe0[i][j][r], ro1, (ok & !isz) ? (mrow[r] * p.ldo1 + nh) * 4u : RAFT_OOB);
                 }
             } else {   // EPI_GRU_Q
-                float hv[4], zv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = nok & mok[r];
-                    hv[r] = bload(re0, ok ? (mrow[r] * p.lde0 + n) * 4u : RAFT_OOB);
-                    zv[r] = bload(re1, ok ? (mrow[r] * p.lde1 + n) * 4u : RAFT_OOB);
-                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float q = raft_tanh(acc[i][j][r] + bias);
-                    bstore((1.0f - zv[r]) * hv[r] + zv[r] * q, ro0,
+                    bstore((1.0f - pe1[i][j][r]) * pe0[i][j][r] + pe1[i][j][r] * q, ro0,
                            (nok & mok[r]) ? (mrow[r] * p.ldo0 + n) * 4u : RAFT_OOB);
                 }
             }

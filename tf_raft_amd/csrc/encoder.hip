@@ -100,8 +100,10 @@ template <int KH, int KW, int EPI, int STRIDE, int PRE, int STATS, int STEM>
 int launch_tile(const ConvArgs &a, int th, int tn, hipStream_t s) {
     const int tiles = a.B * ((a.H + th - 1) / th) * ((a.W + 15) / 16);
     const int grid = tiles * (a.npad / (64 * tn));
-    const int key = th * 10 + tn;
+    const int key = th * 10 + tn + (raft_conv_deep(a, th, tn, grid) ? 100 : 0);
     switch (key) {
+        case 171: conv_halo_kernel<KH, KW, 7, 1, EPI, STRIDE, PRE, STATS, STEM, 1><<<grid, 256, 0, s>>>(a); break;
+        case 181: conv_halo_kernel<KH, KW, 8, 1, EPI, STRIDE, PRE, STATS, STEM, 1><<<grid, 256, 0, s>>>(a); break;
         case 71: conv_halo_kernel<KH, KW, 7, 1, EPI, STRIDE, PRE, STATS, STEM><<<grid, 256, 0, s>>>(a); break;
         case 72: conv_halo_kernel<KH, KW, 7, 2, EPI, STRIDE, PRE, STATS, STEM><<<grid, 256, 0, s>>>(a); break;
         case 81: conv_halo_kernel<KH, KW, 8, 1, EPI, STRIDE, PRE, STATS, STEM><<<grid, 256, 0, s>>>(a); break;

@@ -55,6 +55,7 @@ class RAFT:
         # three-stream schedule of the loop (RAFT only); RAFT_OVERLAP=0 forces the single-stream loop
         self.overlap = (os.environ.get('RAFT_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
         self._aux = None
+        self._enc_stream = None
         self._state = None
         _dev.require_gpu()
         _dev.lib()
@@ -173,10 +174,23 @@ class RAFT:
         if H % 8 or W % 8:
             raise ValueError(f'H and W must be multiples of 8 (got {H}x{W})')   # model.py:35 uses h//8
         # model.py:70-71 (2 * (image / 255) - 1) is applied by the encoders while they stage the image
+        if self.overlap and not training:
+            # the context encoder does not depend on the feature encoder or the volume: it runs on a side stream
+            # next to them (its one-workgroup-per-CU layers fill the tails of the feature encoder's launches)
+            cur = torch.cuda.current_stream(image1.device)
+            if self._enc_stream is None or self._enc_stream.device != image1.device:
+                self._enc_stream = torch.cuda.Stream(device=image1.device)
+            self._enc_stream.wait_stream(cur)
+            with torch.cuda.stream(self._enc_stream):
+                cnet = self.cnet(image1, training=training, _raw_images=True)      # model.py:82
         fmap1, fmap2 = self.fnet([image1, image2], training=training, _raw_images=True)   # model.py:74
         correlation = CorrBlock(fmap1, fmap2, num_levels=self.corr_levels, radius=self.corr_radius,
                                 alternate=self.alternate_corr)                  # model.py:77
-        cnet = self.cnet(image1, training=training, _raw_images=True)          # model.py:82
+        if self.overlap and not training:
+            cur.wait_stream(self._enc_stream)
+            cnet.as_subclass(torch.Tensor).record_stream(cur)
+        else:
+            cnet = self.cnet(image1, training=training, _raw_images=True)      # model.py:82
 
         h, w = H // 8, W // 8
         st = self._get_state(B, h, w, image1.device)
