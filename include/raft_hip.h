@@ -144,6 +144,13 @@ int raft_conv2d_f32(const float *a0, int lda0, int c0, const float *a1, int lda1
                     int npad, int nvalid, int act, float scale, float *out, int ldo,
                     void *stream);
 
+/* The same convolution for 3x3 kernels by Winograd F(2x2, 3x3) (fp32 arithmetic, 2.25x fewer multiplies; what
+ * cuDNN runs under the reference's Conv2D on a GPU; not bit-identical to the direct kernel).  `wp` = the
+ * transformed kernel G g G^T packed as a 4x4-tap kernel; c0, c1 multiples of 16, npad a multiple of 32. */
+int raft_conv2d_winograd_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                             const float *wp, const float *bias, int B, int H, int W, int npad,
+                             int nvalid, int act, float scale, float *out, int ldo, void *stream);
+
 /* ------------------------------------------------------------------ update block */
 
 typedef struct raft_conv_weights {
@@ -167,6 +174,9 @@ typedef struct raft_basic_update_weights {
     raft_conv_weights gru_zr1, gru_q1, gru_zr2, gru_q2;
     raft_conv_weights fh1_mask0, fh2, mask2;
     raft_conv_weights gru_ctx1, gru_ctx2;
+    /* optional (wp == NULL: not supplied): Winograd F(2x2, 3x3) transformed copies of the 3x3 layers, U = G g G^T
+     * packed as a 4x4-tap kernel (16, Cin/4, npad, 4) -- tf_raft_amd/packing.py pack_conv_winograd */
+    raft_conv_weights convc2_w, convf2_w, conv_w, fh1_mask0_w;
 } raft_basic_update_weights;
 
 /* Device state of the recurrent loop (all caller-owned, (B*h*w) pixels, NHWC):

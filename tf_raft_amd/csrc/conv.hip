@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "conv_halo.h"
+#include "conv_wino.h"
 
 // ------------------------------------------------------------------------------------------------
 // tile selection + dispatch of the implicit-GEMM kernel
@@ -166,6 +167,46 @@ extern "C" int raft_conv2d_f32(const float *a0, int lda0, int c0, const float *a
     a.npad = npad; a.nvalid = nvalid; a.hid = 0; a.scale = scale;
     a.o0 = out; a.ldo0 = ldo;
     return raft_launch_conv(a, kh, kw, act == RAFT_ACT_RELU ? EPI_RELU : EPI_LINEAR, (hipStream_t)stream);
+}
+
+extern "C" int raft_conv2d_winograd_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                                        const float *wp, const float *bias, int B, int H, int W, int npad, int nvalid,
+                                        int act, float scale, float *out, int ldo, void *stream) {
+    RAFT_REQUIRE_PTR(a0);
+    RAFT_REQUIRE_PTR(wp);
+    RAFT_REQUIRE_PTR(bias);
+    RAFT_REQUIRE_PTR(out);
+    RAFT_REQUIRE(c1 == 0 || a1 != nullptr, RAFT_E_NULL);
+    RAFT_REQUIRE(B > 0 && H > 0 && W > 0 && nvalid > 0 && nvalid <= npad && ldo >= nvalid, RAFT_E_SHAPE);
+    RAFT_REQUIRE(lda0 >= c0 && (c1 == 0 || lda1 >= c1), RAFT_E_SHAPE);
+    RAFT_REQUIRE(act == RAFT_ACT_NONE || act == RAFT_ACT_RELU, RAFT_E_UNSUPPORTED);
+    ConvArgs a = {};
+    a.a0 = a0; a.a1 = a1; a.lda0 = lda0; a.lda1 = lda1; a.c0 = c0; a.c1 = c1;
+    a.wp = wp; a.bias = bias; a.B = B; a.H = H; a.W = W;
+    a.npad = npad; a.nvalid = nvalid; a.hid = 0; a.scale = scale;
+    a.o0 = out; a.ldo0 = ldo;
+    return raft_launch_conv_wino(a, act == RAFT_ACT_RELU ? EPI_RELU : EPI_LINEAR, (hipStream_t)stream);
+}
+
+// The 3x3 layers of the update block run either on the direct halo kernel or on the Winograd F(2x2, 3x3) kernel
+// (conv_wino.h) when the caller supplied transformed weights.  RAFT_CONV_WINO is a bit mask over
+// {1: convc2, 2: convf2, 4: conv, 8: fh1_mask0}; unset = RAFT_WINO_DEFAULT (the layers where it measured faster at
+// B = 4).  Read per call so that tests can switch it.
+constexpr int RAFT_WINO_DEFAULT = 13;
+static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
+                          hipStream_t s) {
+    const char *e = getenv("RAFT_CONV_WINO");
+    const int mask = e ? atoi(e) : RAFT_WINO_DEFAULT;
+    if ((mask & bit) && wino.wp != nullptr) {
+        a.wp = wino.wp;
+        a.bias = wino.bias;
+        a.npad = wino.npad;
+        return raft_launch_conv_wino(a, epi, s);
+    }
+    a.wp = direct.wp;
+    a.bias = direct.bias;
+    a.npad = direct.npad;
+    return raft_launch_conv(a, 3, 3, epi, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -479,7 +520,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     {   // cor = relu(convc2(cor))             3x3, 256 -> 192   -> corflo[:, 0:192]
         ConvArgs a = conv_args(wts->convc2, cor1, 256, 256, nullptr, 0, 0, B, h, w, 192, corflo, 256);
-        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+        RAFT_TRY(launch_conv3x3(wts->convc2, wts->convc2_w, 1, a, EPI_RELU, s));
         RAFT_MARK();
     }
     if (ov) RAFT_HIP(hipStreamWaitEvent(sf, ov->e_fh, 0));   // flow of the previous iteration is final
@@ -491,7 +532,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     {   // flo = relu(convf2(flo))             3x3, 128 -> 64    -> corflo[:, 192:256]
         ConvArgs a = conv_args(wts->convf2, flo1, 128, 128, nullptr, 0, 0, B, h, w, 64, corflo + 192, 256);
-        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, sf));
+        RAFT_TRY(launch_conv3x3(wts->convf2, wts->convf2_w, 2, a, EPI_RELU, sf));
         RAFT_MARK();
     }
     if (ov) {
@@ -500,7 +541,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     {   // out = relu(conv(cat[cor, flo]))     3x3, 256 -> 126   -> x[:, 128:254]; x[:, 254:256] = flow (kept by flowhead2)
         ConvArgs a = conv_args(wts->conv, corflo, 256, 256, nullptr, 0, 0, B, h, w, 126, st->x + 128, XDIM);
-        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+        RAFT_TRY(launch_conv3x3(wts->conv, wts->conv_w, 4, a, EPI_RELU, s));
         RAFT_MARK();
     }
     // ---- SepConvGRU (update.py:51-67): hx = [h | x]; [r*h | x]
@@ -528,7 +569,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     if (ov && ov->have_up) RAFT_HIP(hipStreamWaitEvent(s, ov->e_up, 0));   // mask2 / upsample of the previous iteration
     {   // relu(flow_head.conv1(net)) | relu(mask.0(net))   3x3, 128 -> 256 + 256
         ConvArgs a = conv_args(wts->fh1_mask0, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 512, fm, 512);
-        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+        RAFT_TRY(launch_conv3x3(wts->fh1_mask0, wts->fh1_mask0_w, 8, a, EPI_RELU, s));
         RAFT_MARK();
     }
     if (ov) {

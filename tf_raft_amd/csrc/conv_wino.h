@@ -1,0 +1,218 @@
+// Winograd F(2x2, 3x3) stride-1 'same' convolution on fp32 MFMA (v_mfma_f32_16x16x4_f32) for gfx950.
+//
+// Y = A^T [ (G g G^T) (.) (B^T d B) ] A with the standard F(2,3) matrices: a 2x2 output tile costs 16 multiplies per
+// (input channel, output channel) instead of 36 -- 2.25x fewer MACs than the direct 3x3 kernel of conv_halo.h, in
+// fp32 arithmetic throughout (the input and output transforms are additions, the weight transform G g G^T is done
+// once on the host in float64 and rounded to fp32: tf_raft_amd/packing.py).  This is the algorithm cuDNN runs for the
+// reference's Conv2D on a GPU; it is NOT bit-identical to an fmaf chain (measured deviation of a layer ~1e-6 relative,
+// tests/test_gpu_kernels.py), so the direct kernel stays selectable (RAFT_CONV_WINO=0).
+//
+//   * GEMM view per winograd tap t = (ty, tx) of 16: D_t[tile][n] = sum_k V_t[tile][k] * U_t[k][n]; an MFMA row is
+//     one 2x2 output tile, an MFMA row block 16 tiles along x (32 x 2 output pixels).  A workgroup owns 4 x 32 output
+//     pixels (two row blocks) x BN = 32*TNW output channels; wave w -> row block w & 1, channel group w >> 1, TNW
+//     column blocks of 16 channels: 16 x TNW accumulators of 4 registers (one per tap: the taps are only combined in
+//     the epilogue).
+//   * K is walked in 16-channel chunks: the 6 x 34 halo tile of the chunk is staged ONCE in LDS (pixel stride 20
+//     floats: conflict-free ds_read_b128 for lanes stepping two pixels, tools/bank_check.py; out-of-image pixels are
+//     zeros through the buffer bounds check).  Lane (tile m, k-quad G) reads the rows of its 4 x 4 patch as b128 =
+//     four channels, applies B^T . B with 8 vector adds per tap row + 4 per tap, and feeds the four channels as the
+//     four k-steps of the tap's MFMAs -- the transformed tile never exists in memory.
+//   * weights: the packed layout [tap][k/4][npad][4] of the direct kernel with 16 "taps"; fragments come straight from
+//     L2 two taps ahead through a 4-slot register ring (the two waves of a channel group share them in L1).
+//   * epilogue: A^T . A over the 16 accumulators of a column block (lane-local: 24 adds per tile), bias, relu, scale.
+#pragma once
+#include <stdlib.h>
+
+#include "conv_mfma.h"
+
+template <int TNW, int EPI>
+__global__ void __launch_bounds__(256, 2) conv_wino_kernel(ConvArgs p) {
+    constexpr int RB = 2, TW = 32, TH = 2 * RB;
+    constexpr int HH = TH + 2, HWP = TW + 2, HP = HH * HWP;   // 6 x 34 halo pixels
+    constexpr int LDA = 20;                                    // floats per halo pixel in LDS (16 used)
+    constexpr int NA = (HP * 4 + 255) / 256;                   // float4 items per thread per chunk
+    constexpr int A_BUF = HP * LDA + 4;                        // + one dummy 16-byte slot for padding items
+    constexpr int BN = 32 * TNW;
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU, "winograd kernel: linear / relu epilogues");
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int G = lane >> 4, LR = lane & 15;
+    const int rb = w & 1, cg = w >> 1;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int ntn = p.npad / BN;
+    const int M = p.B * p.H * p.W;
+
+    int bid = blockIdx.x;   // XCD-aware remap (see conv_halo.h)
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = bid / ntn, nt = bid - mt * ntn;
+    const int tx0 = mt % tiles_x, ty0 = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
+    const int y0 = ty0 * TH, x0 = tx0 * TW;
+    const int n0 = nt * BN;
+    const int cin = p.c0 + p.c1;
+    const int nch = cin >> 4;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.a0, 0, (int)((((long)M - 1) * p.lda0 + p.c0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.c1 ? p.a1 : p.a0), 0, p.c1 ? (int)((((long)M - 1) * p.lda1 + p.c1) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.wp, 0, (int)((long)16 * cin * p.npad * 4), 0x00020000);
+
+    // ---- halo staging: item = (halo pixel, 16-byte channel quad of the chunk)
+    int pix[NA], lds_off[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int item = tid + 256 * i;
+        const int hp = item >> 2, c4 = item & 3;
+        const int hy = hp / HWP, hx = hp - hy * HWP;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = (hp < HP) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
+        pix[i] = ok ? (b * p.H + yy) * p.W + xx : -1;
+        lds_off[i] = hp < HP ? hp * LDA + c4 * 4 : HP * LDA;
+    }
+    f32x4 ra[NA];
+    auto gload = [&](int c) {
+        const int ch = c * 16;
+        const bool first = ch < p.c0;
+        const int ld = first ? p.lda0 : p.lda1;
+        const int chl = (first ? ch : ch - p.c0) + (tid & 3) * 4;
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                ra[i] = raft_buffer_load_f4(rs0, pix[i] >= 0 ? (unsigned)((pix[i] * ld + chl) * 4) : RAFT_OOB);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                ra[i] = raft_buffer_load_f4(rs1, pix[i] >= 0 ? (unsigned)((pix[i] * ld + chl) * 4) : RAFT_OOB);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *(f32x4 *)(smem + buf * A_BUF + lds_off[i]) = ra[i];
+    };
+
+    // ---- fragments
+    const int a_lane = ((2 * rb) * HWP + 2 * LR) * LDA + G * 4;          // patch origin of tile LR in row block rb
+    const unsigned b_lane = (unsigned)(((G * p.npad) + n0 + cg * 16 * TNW + LR) * 16);   // bytes
+    auto patch_row = [&](int buf, int r, f32x4 *d) {                       // d[j] = patch(r, j), j = 0..3
+        const float *base = smem + buf * A_BUF + a_lane + r * HWP * LDA;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = *(const f32x4 *)(base + j * LDA);
+    };
+    f32x4 fb[4][TNW];
+    auto frag_b = [&](int c, int t, f32x4 *bf) {
+        const unsigned row = (unsigned)((t * (cin >> 2) + c * 4) * p.npad) * 16u;   // wave-uniform bytes
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+            bf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(b_lane + j * 256), (int)row, 0));
+    };
+
+    f32x4 acc[16][TNW];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    frag_b(0, 0, fb[0]);
+    frag_b(0, 1, fb[1]);
+    lstore(0);
+    __syncthreads();
+    if (nch > 1) gload(1);
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < nch;
+        f32x4 d1[4], d2[4];                                   // patch rows 1 and 2 serve tap rows 0..3
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty) {
+            // B^T over the patch rows: ty 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+            f32x4 R[4];
+            if (ty == 0) {
+                f32x4 d0[4];
+                patch_row(buf, 0, d0);
+                patch_row(buf, 2, d2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) R[j] = d0[j] - d2[j];
+                patch_row(buf, 1, d1);
+            } else if (ty == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) R[j] = d1[j] + d2[j];
+            } else if (ty == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) R[j] = d2[j] - d1[j];
+            } else {
+                f32x4 d3[4];
+                patch_row(buf, 3, d3);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) R[j] = d1[j] - d3[j];
+                // every LDS read of this chunk has been issued: hand the other buffer over
+                if (more) {
+                    lstore(buf ^ 1);
+                    if (c + 2 < nch) gload(c + 2);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int tx = 0; tx < 4; ++tx) {
+                const int t = ty * 4 + tx;
+                f32x4 V;
+                if (tx == 0) V = R[0] - R[2];
+                else if (tx == 1) V = R[1] + R[2];
+                else if (tx == 2) V = R[2] - R[1];
+                else V = R[1] - R[3];
+                if (t + 2 < 16)
+                    frag_b(c, t + 2, fb[(t + 2) & 3]);
+                else if (more)
+                    frag_b(c + 1, t + 2 - 16, fb[(t + 2) & 3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[e], fb[t & 3][j][e], acc[t][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane owns channel n; register r of an accumulator is tile m = 4G + r of the row block
+    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + p.nvalid) * 4), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const int n = n0 + (cg * TNW + j) * 16 + LR;
+        const bool nok = n < p.nvalid;
+        const float bias = p.bias[n];                         // bias has npad entries
+        // A^T over the tap rows: T[i][tx], i = 0: M0 + M1 + M2, i = 1: M1 - M2 - M3
+        f32x4 T[2][4];
+#pragma unroll
+        for (int tx = 0; tx < 4; ++tx) {
+            T[0][tx] = (acc[tx][j] + acc[4 + tx][j]) + acc[8 + tx][j];
+            T[1][tx] = (acc[4 + tx][j] - acc[8 + tx][j]) - acc[12 + tx][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 ya = (T[i][0] + T[i][1]) + T[i][2], yb = (T[i][1] - T[i][2]) - T[i][3];
+            const int yy = y0 + 2 * rb + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xx = x0 + 2 * (4 * G + r);
+#pragma unroll
+                for (int jx = 0; jx < 2; ++jx) {
+                    float v = (jx ? yb[r] : ya[r]) + bias;
+                    if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                    v *= p.scale;
+                    const bool ok = nok & (yy < p.H) & (xx + jx < p.W);
+                    const unsigned m = (unsigned)((b * p.H + yy) * p.W + xx + jx);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro0,
+                                                          ok ? (int)((m * p.ldo0 + n) * 4u) : (int)RAFT_OOB, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// launcher (conv_wino.hip); `a.wp` holds the winograd-transformed weights packed as a 4x4-tap kernel
+int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s);

@@ -47,6 +47,26 @@ def pack_conv(kernel: np.ndarray, bias: np.ndarray,
     return np.ascontiguousarray(wp), b, npad
 
 
+# Winograd F(2x2, 3x3) weight transform (Lavin & Gray 2016): U = G g G^T
+_WINO_G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=np.float64)
+
+
+def winograd_kernel(kernel: np.ndarray) -> np.ndarray:
+    """(3, 3, Cin, Cout) -> (4, 4, Cin, Cout): U[ty, tx] = sum_{u,v} G[ty, u] G[tx, v] g[u, v], evaluated in float64
+    and rounded once to float32 (the entries of G are dyadic, so only the additions round)."""
+    k = np.asarray(kernel, dtype=np.float64)
+    if k.shape[:2] != (3, 3):
+        raise ValueError(f'winograd_kernel expects a 3x3 kernel, got {k.shape[:2]}')
+    return np.einsum('au,bv,uvio->abio', _WINO_G, _WINO_G, k).astype(np.float32)
+
+
+def pack_conv_winograd(kernel: np.ndarray, bias: np.ndarray,
+                       sources: Sequence[Tuple[int, int]] = None) -> Tuple[np.ndarray, np.ndarray, int]:
+    """``pack_conv`` of the winograd-transformed kernel: the packed layout with 16 taps, consumed by
+    ``conv_wino_kernel`` (csrc/conv_wino.h)."""
+    return pack_conv(winograd_kernel(kernel), bias, sources)
+
+
 def fuse_n(weights: Dict[str, np.ndarray], names: Sequence[str]):
     """Concatenate several convolutions over the same input along the output-channel axis."""
     k = np.concatenate([weights[f'{n}/kernel'] for n in names], axis=3)
@@ -91,7 +111,16 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     out.append(('fh2', np.ascontiguousarray(w[f'{p}/flow_head/conv2/kernel'], dtype=np.float32).reshape(9, 256, 2),
                 np.asarray(w[f'{p}/flow_head/conv2/bias'], dtype=np.float32), 2))
     conv('mask2', f'{p}/mask/2')
-    return out + ctx
+    out = out + ctx
+    # winograd-transformed copies of the 3x3 layers (same order of fields as raft_basic_update_weights)
+    k, b = fuse_n(w, [f'{p}/flow_head/conv1', f'{p}/mask/0'])
+    for field, kk, bb_, src in (('convc2_w', w[f'{p}/encoder/convc2/kernel'], w[f'{p}/encoder/convc2/bias'], None),
+                                ('convf2_w', w[f'{p}/encoder/convf2/kernel'], w[f'{p}/encoder/convf2/bias'], None),
+                                ('conv_w', w[f'{p}/encoder/conv/kernel'], w[f'{p}/encoder/conv/bias'], None),
+                                ('fh1_mask0_w', k, b, None)):
+        wp, bb, npad = pack_conv_winograd(kk, bb_, src)
+        out.append((field, wp, bb, npad))
+    return out
 
 
 def pack_small_update(weights: Dict[str, np.ndarray], prefix: str = 'update_block'):

@@ -53,5 +53,26 @@ for name, kh, kw, cin, cpad, cout in LAYERS:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         row.append(f'{tile}:{flops / ms / 1e9:6.1f}TF {ms*1e3:6.1f}us')
+    if kh == 3 and kw == 3:      # Winograd F(2x2, 3x3) kernel, 32- and 64-channel workgroups (TFLOP/s of the DIRECT algorithm's FLOPs)
+        wpw, bw, npw = packing.pack_conv_winograd(k, np.zeros(cout, np.float32), [(cin, cpad)])
+        wpw_d, bw_d = _dev.to_device(wpw), _dev.to_device(bw)
+        for tnw in ('1', '2'):
+            os.environ['RAFT_WINO_TNW'] = tnw
+
+            def runw():
+                check(lib.raft_conv2d_winograd_f32(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wpw_d), _dev.ptr(bw_d), B, H, W,
+                                                   npw, cout, 1, 1.0, _dev.ptr(out), cout, _dev.stream_ptr()))
+            for _ in range(3):
+                runw()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                runw()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            row.append(f'wino{tnw}:{flops / ms / 1e9:6.1f}TF {ms*1e3:6.1f}us')
+        os.environ.pop('RAFT_WINO_TNW', None)
     print(f'{name:10s} K={kh*kw*cin:5d} N={cout:4d} | ' + ' | '.join(row), flush=True)
 os.environ.pop('RAFT_CONV_TILE', None)
