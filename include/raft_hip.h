@@ -260,6 +260,9 @@ typedef struct raft_encoder_weights {
     raft_conv_weights conv2;
     const float *in_gamma[19];
     const float *in_beta[19];
+    /* optional (wp == NULL: absent): Winograd F(2x2, 3x3) transformed copies of block[i][0] (when it has
+     * stride 1) and block[i][1], packed as 4x4-tap kernels (see raft_conv2d_winograd_f32) */
+    raft_conv_weights block_w[6][2];
 } raft_encoder_weights;
 
 int64_t raft_encoder_workspace_floats(const raft_encoder_weights *w, int n, int H, int W);

@@ -186,8 +186,24 @@ def test_pack_encoder_folds_batch_norm_and_covers_every_layer(rng):
     convs, norms, dims = packing.pack_encoder(wts, 'cnet', 'batch')
     assert dims == (64, 64, 96, 128, 256) and norms == []
     fields = [f for f, *_ in convs]
-    assert fields[0] == 'conv1' and fields[-1] == 'conv2' and len(fields) == 1 + 6 * 2 + 2 + 1
+    direct = [f for f in fields if not (isinstance(f, tuple) and f[0] == 'block_w')]
+    assert direct[0] == 'conv1' and direct[-1] == 'conv2' and len(direct) == 1 + 6 * 2 + 2 + 1
     assert ('block', 2, 2) in fields and ('block', 4, 2) in fields and ('block', 0, 2) not in fields
+    # Winograd copies: every stride-1 3x3 convolution (all conv2, and conv1 of the blocks without a down-sampling branch)
+    wino = sorted(f for f in fields if isinstance(f, tuple) and f[0] == 'block_w')
+    assert wino == sorted([('block_w', b, 1) for b in range(6)] + [('block_w', b, 0) for b in (0, 1, 3, 5)])
+    by_field = {f: (wp, bb, npad) for f, wp, bb, npad in convs}
+    wp_w, _, npad_w = by_field[('block_w', 3, 1)]
+    assert wp_w.shape == (16, 96 // 4, npad_w, 4) and npad_w == 128
+    # U = G g G^T: the four corner taps are the corner kernel entries, and summing U over taps reproduces sum(g) * 2.25
+    name = 'cnet/layer2/1/conv2'
+    kf3, _ = packing._fold_bn(wts[f'{name}/kernel'], wts[f'{name}/bias'],
+                              {kk[len('cnet/'):]: v for kk, v in wts.items() if kk.startswith('cnet/')}, 'layer2/1/norm2')
+    U = packing.winograd_kernel(kf3)
+    np.testing.assert_array_equal(U[0, 0], kf3[0, 0])
+    np.testing.assert_array_equal(U[3, 3], kf3[2, 2])
+    np.testing.assert_allclose(U[1, 1], kf3.sum(axis=(0, 1)) / 4, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(wp_w[5].transpose(0, 2, 1).reshape(96, npad_w)[:, :96], U[1, 1], rtol=0, atol=0)
     # folded conv == conv followed by inference batch norm
     name = 'cnet/layer2/0/conv2'
     k, bias = wts[f'{name}/kernel'], wts[f'{name}/bias']
@@ -208,6 +224,7 @@ def test_pack_encoder_folds_batch_norm_and_covers_every_layer(rng):
     assert small[2] == (32, 32, 64, 96, 160) and small[1] == []
     enc = _ffi.EncoderWeights()
     assert len(enc.in_gamma) == 19 and len(enc.block) == 6 and len(enc.block[0]) == 3
+    assert len(enc.block_w) == 6 and len(enc.block_w[0]) == 2
 
 
 # ---------------------------------------------------------------- C ABI

@@ -37,7 +37,7 @@ class SmallUpdateWeights(C.Structure):
 class EncoderWeights(C.Structure):
     _fields_ = [('c0', C.c_int), ('c1', C.c_int), ('c2', C.c_int), ('c3', C.c_int), ('cout', C.c_int),
                 ('norm', C.c_int), ('conv1', ConvWeights), ('block', (ConvWeights * 3) * 6), ('conv2', ConvWeights),
-                ('in_gamma', C.c_void_p * 19), ('in_beta', C.c_void_p * 19)]
+                ('in_gamma', C.c_void_p * 19), ('in_beta', C.c_void_p * 19), ('block_w', (ConvWeights * 2) * 6)]
 
 
 NORM_NONE, NORM_INSTANCE, NORM_FOLDED = 0, 1, 2

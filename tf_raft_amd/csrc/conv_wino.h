@@ -25,7 +25,10 @@
 
 #include "conv_mfma.h"
 
-template <int TNW, int EPI>
+// PRE / STATS / EPI_RES serve the encoders exactly as in conv_halo.h: PRE applies relu(x * scale[b][c] + shift[b][c])
+// while the halo tile is staged (instance norm + relu of the producer), STATS writes per-(workgroup, row block)
+// (sum, sum of squares) of the raw output per channel [2 * pixel tile + rb][npad][2], EPI_RES is the ResBlock tail.
+template <int TNW, int EPI, int PRE = 0, int STATS = 0>
 __global__ void __launch_bounds__(256, 2) conv_wino_kernel(ConvArgs p) {
     constexpr int RB = 2, TW = 32, TH = 2 * RB;
     constexpr int HH = TH + 2, HWP = TW + 2, HP = HH * HWP;   // 6 x 34 halo pixels
@@ -33,7 +36,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(ConvArgs p) {
     constexpr int NA = (HP * 4 + 255) / 256;                   // float4 items per thread per chunk
     constexpr int A_BUF = HP * LDA + 4;                        // + one dummy 16-byte slot for padding items
     constexpr int BN = 32 * TNW;
-    static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU, "winograd kernel: linear / relu epilogues");
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES, "winograd kernel: linear / relu / residual epilogues");
     __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -74,9 +77,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(ConvArgs p) {
         pix[i] = ok ? (b * p.H + yy) * p.W + xx : -1;
         lds_off[i] = hp < HP ? hp * LDA + c4 * 4 : HP * LDA;
     }
-    f32x4 ra[NA];
+    f32x4 ra[NA], pre_sc, pre_sh;
     auto gload = [&](int c) {
         const int ch = c * 16;
+        if (PRE) {
+            pre_sc = *(const f32x4 *)(p.pre_scale + (long)b * cin + ch + (tid & 3) * 4);
+            pre_sh = *(const f32x4 *)(p.pre_shift + (long)b * cin + ch + (tid & 3) * 4);
+        }
         const bool first = ch < p.c0;
         const int ld = first ? p.lda0 : p.lda1;
         const int chl = (first ? ch : ch - p.c0) + (tid & 3) * 4;
@@ -92,7 +99,14 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(ConvArgs p) {
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *(f32x4 *)(smem + buf * A_BUF + lds_off[i]) = ra[i];
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v = ra[i];
+            if (PRE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pix[i] >= 0 ? fmaxf(fmaf(v[e], pre_sc[e], pre_sh[e]), 0.f) : 0.f;
+            }
+            *(f32x4 *)(smem + buf * A_BUF + lds_off[i]) = v;
+        }
     };
 
     // ---- fragments
@@ -180,11 +194,15 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(ConvArgs p) {
     // ---- epilogue: lane owns channel n; register r of an accumulator is tile m = 4G + r of the row block
     const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + p.nvalid) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t re0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(EPI == EPI_RES ? (const void *)p.e0 : (const void *)p.o0), 0,
+        EPI == EPI_RES ? (int)((((long)M - 1) * p.lde0 + p.nvalid) * 4) : 0, 0x00020000);
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
         const int n = n0 + (cg * TNW + j) * 16 + LR;
         const bool nok = n < p.nvalid;
         const float bias = p.bias[n];                         // bias has npad entries
+        float s1 = 0.f, s2 = 0.f;
         // A^T over the tap rows: T[i][tx], i = 0: M0 + M1 + M2, i = 1: M1 - M2 - M3
         f32x4 T[2][4];
 #pragma unroll
@@ -196,23 +214,53 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(ConvArgs p) {
         for (int i = 0; i < 2; ++i) {
             const f32x4 ya = (T[i][0] + T[i][1]) + T[i][2], yb = (T[i][1] - T[i][2]) - T[i][3];
             const int yy = y0 + 2 * rb + i;
+            float xv[4][2];
+            if (EPI == EPI_RES) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int jx = 0; jx < 2; ++jx) {
+                        const int xx = x0 + 2 * (4 * G + r) + jx;
+                        const bool ok = nok & (yy < p.H) & (xx < p.W);
+                        const unsigned m = (unsigned)((b * p.H + yy) * p.W + xx);
+                        xv[r][jx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                  re0, ok ? (int)((m * p.lde0 + n) * 4u) : (int)RAFT_OOB, 0, 0));
+                    }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int xx = x0 + 2 * (4 * G + r);
 #pragma unroll
                 for (int jx = 0; jx < 2; ++jx) {
                     float v = (jx ? yb[r] : ya[r]) + bias;
-                    if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-                    v *= p.scale;
-                    const bool ok = nok & (yy < p.H) & (xx + jx < p.W);
+                    const bool mok = (yy < p.H) & (xx + jx < p.W);
+                    if (EPI == EPI_RES) {
+                        v = fmaxf(xv[r][jx] + fmaxf(v, 0.f), 0.f);
+                    } else {
+                        if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                        v *= p.scale;
+                    }
+                    if (STATS && mok) {
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
                     const unsigned m = (unsigned)((b * p.H + yy) * p.W + xx + jx);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro0,
-                                                          ok ? (int)((m * p.ldo0 + n) * 4u) : (int)RAFT_OOB, 0, 0);
+                                                          (nok & mok) ? (int)((m * p.ldo0 + n) * 4u) : (int)RAFT_OOB, 0, 0);
                 }
             }
+        }
+        if (STATS) {   // lanes LR, LR+16, LR+32, LR+48 hold the same channel
+            s1 += __shfl_xor(s1, 16, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (G == 0) *(float2 *)(p.stats + ((long)(2 * mt + rb) * p.npad + n) * 2) = make_float2(s1, s2);
         }
     }
 }
 
 // launcher (conv_wino.hip); `a.wp` holds the winograd-transformed weights packed as a 4x4-tap kernel
+// epi: EPI_LINEAR / EPI_RELU / EPI_RES; a.pre_scale != NULL selects PRE, a.stats != NULL selects STATS (the encoder
+// combinations: LINEAR + STATS (+ PRE), RELU, RES).  Stats entries per image: 2 * ceil(H/4) * ceil(W/32).
 int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s);

@@ -3,11 +3,21 @@
 
 template <int TNW>
 static int launch_wino(const ConvArgs &a, int epi, int grid, hipStream_t s) {
-    switch (epi) {
-        case EPI_LINEAR: conv_wino_kernel<TNW, EPI_LINEAR><<<grid, 256, 0, s>>>(a); break;
-        case EPI_RELU: conv_wino_kernel<TNW, EPI_RELU><<<grid, 256, 0, s>>>(a); break;
-        default: return RAFT_E_UNSUPPORTED;
-    }
+    const bool pre = a.pre_scale != nullptr, stats = a.stats != nullptr;
+    if (epi == EPI_LINEAR && stats && pre)
+        conv_wino_kernel<TNW, EPI_LINEAR, 1, 1><<<grid, 256, 0, s>>>(a);
+    else if (epi == EPI_LINEAR && stats)
+        conv_wino_kernel<TNW, EPI_LINEAR, 0, 1><<<grid, 256, 0, s>>>(a);
+    else if (pre || stats)
+        return RAFT_E_UNSUPPORTED;
+    else if (epi == EPI_LINEAR)
+        conv_wino_kernel<TNW, EPI_LINEAR><<<grid, 256, 0, s>>>(a);
+    else if (epi == EPI_RELU)
+        conv_wino_kernel<TNW, EPI_RELU><<<grid, 256, 0, s>>>(a);
+    else if (epi == EPI_RES)
+        conv_wino_kernel<TNW, EPI_RES><<<grid, 256, 0, s>>>(a);
+    else
+        return RAFT_E_UNSUPPORTED;
     return raft_launch_status();
 }
 
@@ -15,7 +25,8 @@ int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s) {
     if (a.c0 <= 0 || a.c0 % 16 || a.c1 < 0 || a.c1 % 16 || a.npad <= 0 || a.npad % 32) return RAFT_E_UNSUPPORTED;
     if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
     if (!raft_aligned16(a.a0) || !raft_aligned16(a.wp) || (a.c1 && !raft_aligned16(a.a1))) return RAFT_E_ALIGN;
-    if (a.init || a.pre_scale || a.stats || (a.Hi && (a.Hi != a.H || a.Wi != a.W))) return RAFT_E_UNSUPPORTED;
+    if (a.init || (a.Hi && (a.Hi != a.H || a.Wi != a.W))) return RAFT_E_UNSUPPORTED;
+    if (epi == EPI_RES && (a.e0 == nullptr || (int64_t)a.B * a.H * a.W * a.lde0 * 4 >= ((int64_t)1 << 31))) return RAFT_E_UNSUPPORTED;
     {   // 32-bit buffer offsets: every operand must span < 2 GiB
         const int64_t M = (int64_t)a.B * a.H * a.W, lim = (int64_t)1 << 31;
         if (((M - 1) * a.lda0 + a.c0) * 4 >= lim || (a.c1 && ((M - 1) * a.lda1 + a.c1) * 4 >= lim)) return RAFT_E_UNSUPPORTED;

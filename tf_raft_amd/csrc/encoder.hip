@@ -14,6 +14,7 @@
 //   TF semantics: stride-2 'same' convolutions pad asymmetrically (extra pixel after); the 1x1 stride-2
 //   down-sampling convolution is 'valid'.
 #include "conv_halo.h"
+#include "conv_wino.h"
 
 namespace {
 
@@ -179,7 +180,9 @@ extern "C" int64_t raft_encoder_workspace_floats(const raft_encoder_weights *w, 
     if (w->c2 > cmax) cmax = w->c2;
     if (w->c3 > cmax) cmax = w->c3;
     const int64_t act = align4((int64_t)n * h1 * w1 * cmax);
-    const int64_t tiles = (int64_t)n * ((h1 + 6) / 7) * ((w1 + 15) / 16);
+    int64_t tiles = (int64_t)n * ((h1 + 6) / 7) * ((w1 + 15) / 16);
+    const int64_t tiles_w = (int64_t)n * 2 * ((h1 + 3) / 4) * ((w1 + 31) / 32);   // winograd kernel: entries per row block
+    if (tiles_w > tiles) tiles = tiles_w;
     const int64_t part = align4(tiles * 256 * 2);
     const int64_t ss = align4((int64_t)n * 256 * 2 * 3);
     return align4((int64_t)n * H * W * 4) + 5 * act + part + ss;
@@ -206,7 +209,13 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
     if (w->c2 > cmax) cmax = w->c2;
     if (w->c3 > cmax) cmax = w->c3;
     const int64_t act = align4((int64_t)n * h1 * w1 * cmax);
-    const int64_t tiles_max = (int64_t)n * ((h1 + 6) / 7) * ((w1 + 15) / 16);
+    int64_t tiles_max = (int64_t)n * ((h1 + 6) / 7) * ((w1 + 15) / 16);
+    {
+        const int64_t tiles_w = (int64_t)n * 2 * ((h1 + 3) / 4) * ((w1 + 31) / 32);
+        if (tiles_w > tiles_max) tiles_max = tiles_w;
+    }
+    const char *wino_env = getenv("RAFT_ENC_WINO");   // 0: direct 3x3 kernels everywhere (A/B timing, parity tests)
+    const bool use_wino = wino_env ? atoi(wino_env) != 0 : true;
     EncBufs b;
     float *p = workspace;
     b.img4 = p; p += align4((int64_t)n * H * W * 4);
@@ -230,9 +239,12 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
     }
 
     // one convolution (+ instance-norm moments -> scale/shift slot `slot`)
-    auto conv = [&](EncKind kind, const raft_conv_weights &cw, const float *in, int cin, int Hi, int Wi, int Ho, int Wo,
+    auto conv = [&](EncKind kind, const raft_conv_weights &cw_direct, const float *in, int cin, int Hi, int Wi, int Ho, int Wo,
                     int pt, int pl, int cout, int epi, float *dst, const float *res, const float *pre_sc,
-                    const float *pre_sh, int slot, const float *gamma, const float *beta) -> int {
+                    const float *pre_sh, int slot, const float *gamma, const float *beta,
+                    const raft_conv_weights *cw_wino = nullptr) -> int {
+        const bool wino = use_wino && kind == ENC_3x3_S1 && cw_wino && cw_wino->wp != nullptr;
+        const raft_conv_weights &cw = wino ? *cw_wino : cw_direct;
         ConvArgs a = {};
         a.a0 = in; a.lda0 = (kind == ENC_STEM) ? 4 : cin; a.c0 = (kind == ENC_STEM) ? 7 * 32 : cin;
         a.wp = cw.wp; a.bias = cw.bias; a.npad = cw.npad; a.nvalid = cout;
@@ -243,10 +255,10 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
         a.stats = (inorm && slot >= 0) ? b.part : nullptr;
         int th, tn;
         enc_pick(Ho, cw.npad, &th, &tn);
-        int rc = enc_conv(a, kind, epi, th, tn, s);
+        int rc = wino ? raft_launch_conv_wino(a, epi, s) : enc_conv(a, kind, epi, th, tn, s);
         if (rc != RAFT_OK) return rc;
         if (a.stats) {
-            const int tiles = ((Ho + th - 1) / th) * ((Wo + 15) / 16);
+            const int tiles = wino ? 2 * ((Ho + 3) / 4) * ((Wo + 31) / 32) : ((Ho + th - 1) / th) * ((Wo + 15) / 16);
             dim3 grid((cout + 63) / 64, n);
             in_finalize_kernel<<<grid, 1024, 0, s>>>(b.part, tiles, cw.npad, cout, gamma, beta, 1.0 / ((double)Ho * Wo),
                                                      ss_slot[slot][0], ss_slot[slot][1]);
@@ -292,9 +304,9 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
         const int ni = 1 + blk * 3;   // index of this block's norm1 in in_gamma / in_beta
         if (inorm) {
             RAFT_TRY(conv(k1, c1, x, C, Hc, Wc, Ho, Wo, p1t, p1l, F, EPI_LINEAR, b.r1, nullptr, nullptr, nullptr, 0,
-                              w->in_gamma[ni], w->in_beta[ni]));
+                              w->in_gamma[ni], w->in_beta[ni], &w->block_w[blk][0]));
             RAFT_TRY(conv(ENC_3x3_S1, c2, b.r1, F, Ho, Wo, Ho, Wo, 1, 1, F, EPI_LINEAR, b.r2, nullptr, ss_slot[0][0],
-                              ss_slot[0][1], 1, w->in_gamma[ni + 1], w->in_beta[ni + 1]));
+                              ss_slot[0][1], 1, w->in_gamma[ni + 1], w->in_beta[ni + 1], &w->block_w[blk][1]));
             if (stride == 2) {
                 RAFT_REQUIRE(cd.wp != nullptr, RAFT_E_NULL);
                 RAFT_TRY(conv(ENC_1x1_S2, cd, x, C, Hc, Wc, Ho, Wo, 0, 0, F, EPI_LINEAR, b.rd, nullptr, nullptr, nullptr, 2,
@@ -305,7 +317,7 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
             }
         } else {
             RAFT_TRY(conv(k1, c1, x, C, Hc, Wc, Ho, Wo, p1t, p1l, F, EPI_RELU, b.r1, nullptr, nullptr, nullptr, -1, nullptr,
-                              nullptr));
+                              nullptr, &w->block_w[blk][0]));
             const float *shortcut = x;
             if (stride == 2) {
                 RAFT_REQUIRE(cd.wp != nullptr, RAFT_E_NULL);
@@ -314,7 +326,7 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
                 shortcut = b.rd;
             }
             RAFT_TRY(conv(ENC_3x3_S1, c2, b.r1, F, Ho, Wo, Ho, Wo, 1, 1, F, EPI_RES, y, shortcut, nullptr, nullptr, -1,
-                              nullptr, nullptr));
+                              nullptr, nullptr, &w->block_w[blk][1]));
         }
         float *t = x; x = y; y = t;
         C = F; Hc = Ho; Wc = Wo;

@@ -109,6 +109,8 @@ class _Encoder:
                 c.conv1 = cw
             elif field == 'conv2':
                 c.conv2 = cw
+            elif field[0] == 'block_w':
+                c.block_w[field[1]][field[2]] = cw
             else:
                 c.block[field[1]][field[2]] = cw
         for idx, _, _ in norms:
