@@ -28,8 +28,11 @@
 // PRE / STATS / EPI_RES serve the encoders exactly as in conv_halo.h: PRE applies relu(x * scale[b][c] + shift[b][c])
 // while the halo tile is staged (instance norm + relu of the producer), STATS writes per-(workgroup, row block)
 // (sum, sum of squares) of the raw output per channel [2 * pixel tile + rb][npad][2], EPI_RES is the ResBlock tail.
-template <int TNW, int EPI, int PRE = 0, int STATS = 0>
-__global__ void __launch_bounds__(256, 2) conv_wino_kernel(ConvArgs p) {
+// SB = 1 pins the weight-fragment prefetch two taps ahead with a scheduling barrier (see the main loop); it costs
+// registers (two workgroups per CU instead of three at TNW = 1), so the launcher uses it where two resident workgroups
+// per CU cover the grid anyway.
+template <int TNW, int EPI, int PRE = 0, int STATS = 0, int SB = 0>
+__global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_wino_kernel(ConvArgs p) {
     constexpr int RB = 2, TW = 32, TH = 2 * RB;
     constexpr int HH = TH + 2, HWP = TW + 2, HP = HH * HWP;   // 6 x 34 halo pixels
     constexpr int LDA = 20;                                    // floats per halo pixel in LDS (16 used)
@@ -137,38 +140,42 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(ConvArgs p) {
     lstore(0);
     __syncthreads();
     if (nch > 1) gload(1);
+    // patch rows: dA holds row 0, later row 3; dB row 2; dC row 1.  Every LDS read is issued one tap row ahead of its
+    // use (row 1 under the MFMAs of tap row 0, row 3 under tap row 1, the NEXT chunk's rows 0 and 2 under tap row 3).
+    f32x4 dA[4], dB[4], dC[4];
+    patch_row(0, 0, dA);
+    patch_row(0, 2, dB);
     for (int c = 0; c < nch; ++c) {
         const int buf = c & 1;
         const bool more = c + 1 < nch;
-        f32x4 d1[4], d2[4];                                   // patch rows 1 and 2 serve tap rows 0..3
 #pragma unroll
         for (int ty = 0; ty < 4; ++ty) {
             // B^T over the patch rows: ty 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
             f32x4 R[4];
             if (ty == 0) {
-                f32x4 d0[4];
-                patch_row(buf, 0, d0);
-                patch_row(buf, 2, d2);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) R[j] = d0[j] - d2[j];
-                patch_row(buf, 1, d1);
+                for (int j = 0; j < 4; ++j) R[j] = dA[j] - dB[j];
+                patch_row(buf, 1, dC);
             } else if (ty == 1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) R[j] = d1[j] + d2[j];
+                for (int j = 0; j < 4; ++j) R[j] = dC[j] + dB[j];
+                patch_row(buf, 3, dA);
             } else if (ty == 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) R[j] = d2[j] - d1[j];
+                for (int j = 0; j < 4; ++j) R[j] = dB[j] - dC[j];
             } else {
-                f32x4 d3[4];
-                patch_row(buf, 3, d3);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) R[j] = d1[j] - d3[j];
-                // every LDS read of this chunk has been issued: hand the other buffer over
+                for (int j = 0; j < 4; ++j) R[j] = dC[j] - dA[j];
+                // every LDS read of this chunk has been issued and consumed: hand the other buffer over
                 if (more) {
                     lstore(buf ^ 1);
                     if (c + 2 < nch) gload(c + 2);
                 }
                 __syncthreads();
+                if (more) {
+                    patch_row(buf ^ 1, 0, dA);
+                    patch_row(buf ^ 1, 2, dB);
+                }
             }
 #pragma unroll
             for (int tx = 0; tx < 4; ++tx) {
@@ -182,6 +189,9 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(ConvArgs p) {
                     frag_b(c, t + 2, fb[(t + 2) & 3]);
                 else if (more)
                     frag_b(c + 1, t + 2 - 16, fb[(t + 2) & 3]);
+                // keep the weight fetch of tap t + 2 HERE: left alone, the scheduler sinks it next to its use to save
+                // registers and every tap then waits out an L2 round trip (seen in the ISA: load, s_waitcnt, mfma)
+                if (SB) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll

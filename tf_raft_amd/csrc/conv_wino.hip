@@ -1,21 +1,21 @@
 // Winograd F(2x2, 3x3) convolution launcher (kernel: conv_wino.h).
 #include "conv_wino.h"
 
-template <int TNW>
+template <int TNW, int SB>
 static int launch_wino(const ConvArgs &a, int epi, int grid, hipStream_t s) {
     const bool pre = a.pre_scale != nullptr, stats = a.stats != nullptr;
     if (epi == EPI_LINEAR && stats && pre)
-        conv_wino_kernel<TNW, EPI_LINEAR, 1, 1><<<grid, 256, 0, s>>>(a);
+        conv_wino_kernel<TNW, EPI_LINEAR, 1, 1, 0><<<grid, 256, 0, s>>>(a);
     else if (epi == EPI_LINEAR && stats)
-        conv_wino_kernel<TNW, EPI_LINEAR, 0, 1><<<grid, 256, 0, s>>>(a);
+        conv_wino_kernel<TNW, EPI_LINEAR, 0, 1, SB><<<grid, 256, 0, s>>>(a);
     else if (pre || stats)
         return RAFT_E_UNSUPPORTED;
     else if (epi == EPI_LINEAR)
-        conv_wino_kernel<TNW, EPI_LINEAR><<<grid, 256, 0, s>>>(a);
+        conv_wino_kernel<TNW, EPI_LINEAR, 0, 0, SB><<<grid, 256, 0, s>>>(a);
     else if (epi == EPI_RELU)
-        conv_wino_kernel<TNW, EPI_RELU><<<grid, 256, 0, s>>>(a);
+        conv_wino_kernel<TNW, EPI_RELU, 0, 0, SB><<<grid, 256, 0, s>>>(a);
     else if (epi == EPI_RES)
-        conv_wino_kernel<TNW, EPI_RES><<<grid, 256, 0, s>>>(a);
+        conv_wino_kernel<TNW, EPI_RES, 0, 0, SB><<<grid, 256, 0, s>>>(a);
     else
         return RAFT_E_UNSUPPORTED;
     return raft_launch_status();
@@ -39,5 +39,9 @@ int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s) {
     int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) >= 512) ? 2 : 1;
     if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
     const int grid = tiles * (a.npad / (32 * tnw));
-    return tnw == 2 ? launch_wino<2>(a, epi, grid, s) : launch_wino<1>(a, epi, grid, s);
+    // pinned weight prefetch (SB): always at TNW = 2; at TNW = 1 only when two workgroups per CU hold the whole grid
+    const char *sbe = getenv("RAFT_WINO_SB");   // tuning override: 0 / 1
+    const bool sb = sbe ? atoi(sbe) != 0 : (tnw == 2 || grid <= 512);
+    if (tnw == 2) return sb ? launch_wino<2, 1>(a, epi, grid, s) : launch_wino<2, 0>(a, epi, grid, s);
+    return sb ? launch_wino<1, 1>(a, epi, grid, s) : launch_wino<1, 0>(a, epi, grid, s);
 }

@@ -58,6 +58,25 @@ def main():
         ms = timed(run, reps)
         flops = 2.0 * B * H * W * kh * kw * cin * cout
         print(f'conv {name} tile={tile} B={B}: {ms*1e3:.1f} us  {flops / ms / 1e9:.1f} TFLOP/s')
+    elif kind == 'wino':
+        name, tnw = sys.argv[2], sys.argv[3]
+        B = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+        reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+        kh, kw, cin, cpad, cout = LAYERS[name]
+        assert kh == 3 and kw == 3
+        os.environ['RAFT_WINO_TNW'] = tnw
+        k = (rng.normal(size=(kh, kw, cin, cout)) * 0.05).astype(np.float32)
+        wp, b, npad = packing.pack_conv_winograd(k, np.zeros(cout, np.float32), [(cin, cpad)])
+        x = _dev.to_device(rng.normal(size=(B, H, W, cpad)).astype(np.float32))
+        wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
+        out = torch.empty((B, H, W, cout), device=x.device)
+
+        def run():
+            check(lib.raft_conv2d_winograd_f32(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W,
+                                               npad, cout, 1, 1.0, _dev.ptr(out), cout, _dev.stream_ptr()))
+        ms = timed(run, reps)
+        flops = 2.0 * B * H * W * kh * kw * cin * cout
+        print(f'wino {name} tnw={tnw} B={B}: {ms*1e3:.1f} us  {flops / ms / 1e9:.1f} TFLOP/s (direct-algorithm FLOPs)')
     elif kind == 'lookup':
         ver = sys.argv[2]
         B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
