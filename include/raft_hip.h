@@ -151,6 +151,12 @@ int raft_conv2d_winograd_f32(const float *a0, int lda0, int c0, const float *a1,
                              const float *wp, const float *bias, int B, int H, int W, int npad,
                              int nvalid, int act, float scale, float *out, int ldo, void *stream);
 
+/* 1x5 (kh = 1, kw = 5) or 5x1 convolution by 1-D Winograd F(2, 5) (6 multiplies per output pair instead of 10;
+ * fp32, points {0, +-1, +-1/2, inf}).  `wp` = the transformed kernel packed with 6 taps; c0, c1 multiples of 16. */
+int raft_conv1d_winograd_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                             const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
+                             int npad, int nvalid, int act, float scale, float *out, int ldo, void *stream);
+
 /* ------------------------------------------------------------------ update block */
 
 typedef struct raft_conv_weights {
@@ -177,6 +183,9 @@ typedef struct raft_basic_update_weights {
     /* optional (wp == NULL: not supplied): Winograd F(2x2, 3x3) transformed copies of the 3x3 layers, U = G g G^T
      * packed as a 4x4-tap kernel (16, Cin/4, npad, 4) -- tf_raft_amd/packing.py pack_conv_winograd */
     raft_conv_weights convc2_w, convf2_w, conv_w, fh1_mask0_w;
+    /* optional: 1-D Winograd F(2, 5) transformed copies of gru_zr{1,2} / gru_q{1,2}: U = G' g packed as a 6-tap
+     * kernel (6, Cin/4, npad, 4) -- tf_raft_amd/packing.py pack_conv_winograd1d */
+    raft_conv_weights gru_zr1_w, gru_q1_w, gru_zr2_w, gru_q2_w;
 } raft_basic_update_weights;
 
 /* Device state of the recurrent loop (all caller-owned, (B*h*w) pixels, NHWC):

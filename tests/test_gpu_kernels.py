@@ -306,6 +306,60 @@ def test_conv2d_winograd_matches_oracle(rng, shape, tnw, monkeypatch):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize('tnw', ['1', '2'])
+@pytest.mark.parametrize('ksize', [(1, 5), (5, 1)])
+@pytest.mark.parametrize('shape', [(2, 9, 13), (1, 8, 64), (1, 21, 35)])
+def test_conv1d_winograd_matches_oracle(rng, shape, ksize, tnw, monkeypatch):
+    """1-D Winograd F(2, 5) kernel (conv_wino1d.h) against the float64 direct convolution; two sources, N tail."""
+    from oracle import tf_ops
+    from tf_raft_amd import _dev, packing
+    from tf_raft_amd._ffi import check
+    monkeypatch.setenv('RAFT_WINO_TNW', tnw)
+    kh, kw = ksize
+    B, H, W = shape
+    c_a, c_b, cout = 48, 64, 150
+    xa = rng.normal(size=(B, H, W, c_a)).astype(np.float32)
+    xb = rng.normal(size=(B, H, W, c_b)).astype(np.float32)
+    kernel = (rng.normal(size=(kh, kw, c_a + c_b, cout)) * 0.1).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    sa, sb = _dev.to_device(xa), _dev.to_device(xb)
+    wp, b, npad = packing.pack_conv_winograd1d(kernel, bias, [(c_a, 64), (c_b, 64)])
+    assert wp.shape == (6, 32, npad, 4)
+    wp = np.ascontiguousarray(np.concatenate([wp[:, :12], wp[:, 16:]], axis=1))      # drop the all-zero rows 48..63
+    wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
+    out = torch.full((B, H, W, cout), float('nan'), device=sa.device)
+    check(_dev.lib().raft_conv1d_winograd_f32(_dev.ptr(sa), c_a, c_a, _dev.ptr(sb), c_b, c_b, _dev.ptr(wp_d), _dev.ptr(b_d),
+                                              B, H, W, kh, kw, npad, cout, 1, 0.5, _dev.ptr(out), cout, _dev.stream_ptr()),
+          'conv1d_winograd')
+    torch.cuda.synchronize()
+    got = _np(out)
+    x = torch.cat([_t(xa), _t(xb)], dim=-1)
+    want = 0.5 * torch.relu(tf_ops.conv2d(x.double(), _t(kernel).double(), _t(bias).double())).numpy()
+    direct = _conv_device([(xa, 64), (xb, 64)], kernel, bias, act=1, scale=0.5)
+    err, err_direct = float(np.abs(got - want).max()), float(np.abs(direct - want).max())
+    report(f'conv1d winograd {ksize} {shape} tnw {tnw}', max_abs_vs_f64=err, direct_vs_f64=err_direct)
+    assert not np.isnan(got).any()
+    assert err < 2e-5
+
+
+def test_basic_update_block_winograd_gru_matches_direct(rng, monkeypatch):
+    """RAFT_GRU_WINO=15: the four per-iteration SepConvGRU convolutions on the F(2, 5) kernel (gate epilogues + context)."""
+    from tf_raft_amd import weights as wm
+    from tf_raft_amd.layers.update import BasicUpdateBlock
+    wts = wm.init_weights('raft', seed=3, perturb=True)
+    for shape in ((1, 56, 64), (2, 9, 13)):
+        net, inp, corr, flow = _update_inputs(rng, 'raft', *shape)
+        blk = BasicUpdateBlock(filters=128, weights=wts)
+        monkeypatch.setenv('RAFT_GRU_WINO', '0')
+        dn, dm, dd = [_np(t) for t in blk([net, inp, corr, flow])]
+        monkeypatch.setenv('RAFT_GRU_WINO', '15')
+        wn, wmk, wd = [_np(t) for t in blk([net, inp, corr, flow])]
+        report(f'update block F(2,5) GRU vs direct {shape}', net=float(np.abs(wn - dn).max()),
+               mask=float(np.abs(wmk - dm).max()), delta=float(np.abs(wd - dd).max()))
+        assert np.abs(wn - dn).max() < 2e-5 and np.abs(wmk - dm).max() < 5e-5 and np.abs(wd - dd).max() < 5e-5
+        assert np.abs(wn - dn).max() > 0
+
+
 def test_basic_update_block_winograd_layers_match_direct(rng, monkeypatch):
     """RAFT_CONV_WINO=15: all four 3x3 layers of the update block on the winograd kernel."""
     from tf_raft_amd import weights as wm

@@ -6,6 +6,7 @@
 
 #include "conv_halo.h"
 #include "conv_wino.h"
+#include "conv_wino1d.h"
 
 // ------------------------------------------------------------------------------------------------
 // tile selection + dispatch of the implicit-GEMM kernel
@@ -186,6 +187,44 @@ extern "C" int raft_conv2d_winograd_f32(const float *a0, int lda0, int c0, const
     a.npad = npad; a.nvalid = nvalid; a.hid = 0; a.scale = scale;
     a.o0 = out; a.ldo0 = ldo;
     return raft_launch_conv_wino(a, act == RAFT_ACT_RELU ? EPI_RELU : EPI_LINEAR, (hipStream_t)stream);
+}
+
+extern "C" int raft_conv1d_winograd_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                                        const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
+                                        int npad, int nvalid, int act, float scale, float *out, int ldo, void *stream) {
+    RAFT_REQUIRE_PTR(a0);
+    RAFT_REQUIRE_PTR(wp);
+    RAFT_REQUIRE_PTR(bias);
+    RAFT_REQUIRE_PTR(out);
+    RAFT_REQUIRE(c1 == 0 || a1 != nullptr, RAFT_E_NULL);
+    RAFT_REQUIRE(B > 0 && H > 0 && W > 0 && nvalid > 0 && nvalid <= npad && ldo >= nvalid, RAFT_E_SHAPE);
+    RAFT_REQUIRE(lda0 >= c0 && (c1 == 0 || lda1 >= c1), RAFT_E_SHAPE);
+    RAFT_REQUIRE(act == RAFT_ACT_NONE || act == RAFT_ACT_RELU, RAFT_E_UNSUPPORTED);
+    ConvArgs a = {};
+    a.a0 = a0; a.a1 = a1; a.lda0 = lda0; a.lda1 = lda1; a.c0 = c0; a.c1 = c1;
+    a.wp = wp; a.bias = bias; a.B = B; a.H = H; a.W = W;
+    a.npad = npad; a.nvalid = nvalid; a.hid = 0; a.scale = scale;
+    a.o0 = out; a.ldo0 = ldo;
+    return raft_launch_conv_wino1d(a, kh, kw, act == RAFT_ACT_RELU ? EPI_RELU : EPI_LINEAR, (hipStream_t)stream);
+}
+
+// The per-iteration SepConvGRU convolutions: direct halo kernel or 1-D Winograd F(2, 5) (conv_wino1d.h).
+// RAFT_GRU_WINO is a bit mask over {1: gru_zr1, 2: gru_q1, 4: gru_zr2, 8: gru_q2}; unset = RAFT_GRU_WINO_DEFAULT.
+constexpr int RAFT_GRU_WINO_DEFAULT = 15;
+static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int kh,
+                           int kw, int epi, hipStream_t s) {
+    const char *e = getenv("RAFT_GRU_WINO");
+    const int mask = e ? atoi(e) : RAFT_GRU_WINO_DEFAULT;
+    if ((mask & bit) && wino.wp != nullptr) {
+        a.wp = wino.wp;
+        a.bias = wino.bias;
+        a.npad = wino.npad;
+        return raft_launch_conv_wino1d(a, kh, kw, epi, s);
+    }
+    a.wp = direct.wp;
+    a.bias = direct.bias;
+    a.npad = direct.npad;
+    return raft_launch_conv(a, kh, kw, epi, s);
 }
 
 // The 3x3 layers of the update block run either on the direct halo kernel or on the Winograd F(2x2, 3x3) kernel
@@ -548,6 +587,8 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     for (int pass = 0; pass < 2; ++pass) {
         const raft_conv_weights &wzr = pass == 0 ? wts->gru_zr1 : wts->gru_zr2;
         const raft_conv_weights &wq = pass == 0 ? wts->gru_q1 : wts->gru_q2;
+        const raft_conv_weights &wzr_w = pass == 0 ? wts->gru_zr1_w : wts->gru_zr2_w;
+        const raft_conv_weights &wq_w = pass == 0 ? wts->gru_q1_w : wts->gru_q2_w;
         const int kh = pass == 0 ? 1 : 5, kw = pass == 0 ? 5 : 1;
         const float *xm = st->x + CDIM;                      // [motion | flow]; the inp rows live in st->ctx
         const float *ctx = st->ctx + pass * 3 * HDIM;        // [z | r | q] context of this pass
@@ -555,14 +596,14 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
             ConvArgs a = conv_args(wzr, st->net, HDIM, HDIM, xm, XDIM, XDIM - CDIM, B, h, w, 2 * HDIM, zb, HDIM);
             a.hid = HDIM; a.o1 = rh; a.ldo1 = HDIM; a.e0 = st->net; a.lde0 = HDIM;
             a.init = ctx; a.ldi = CTX_LD;
-            RAFT_TRY(raft_launch_conv(a, kh, kw, EPI_GRU_ZR, s));
+            RAFT_TRY(launch_gru_conv(wzr, wzr_w, pass == 0 ? 1 : 4, a, kh, kw, EPI_GRU_ZR, s));
             RAFT_MARK();
         }
         {
             ConvArgs a = conv_args(wq, rh, HDIM, HDIM, xm, XDIM, XDIM - CDIM, B, h, w, HDIM, st->net, HDIM);
             a.e0 = st->net; a.lde0 = HDIM; a.e1 = zb; a.lde1 = HDIM;
             a.init = ctx + 2 * HDIM; a.ldi = CTX_LD;
-            RAFT_TRY(raft_launch_conv(a, kh, kw, EPI_GRU_Q, s));
+            RAFT_TRY(launch_gru_conv(wq, wq_w, pass == 0 ? 2 : 8, a, kh, kw, EPI_GRU_Q, s));
             RAFT_MARK();
         }
     }

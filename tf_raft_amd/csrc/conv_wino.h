@@ -31,12 +31,15 @@
 // SB = 1 pins the weight-fragment prefetch two taps ahead with a scheduling barrier (see the main loop); it costs
 // registers (two workgroups per CU instead of three at TNW = 1), so the launcher uses it where two resident workgroups
 // per CU cover the grid anyway.
-template <int TNW, int EPI, int PRE = 0, int STATS = 0, int SB = 0>
+// CK = 16-channel chunks staged per barrier (1 or 2): CK = 2 halves the barriers of the TNW = 1 kernels, whose chunks
+// are only 64 MFMAs per wave (it needs 12 more staging registers, which the TNW = 2 kernels do not have).
+template <int TNW, int EPI, int PRE = 0, int STATS = 0, int SB = 0, int CK = 1>
 __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_wino_kernel(ConvArgs p) {
     constexpr int RB = 2, TW = 32, TH = 2 * RB;
     constexpr int HH = TH + 2, HWP = TW + 2, HP = HH * HWP;   // 6 x 34 halo pixels
-    constexpr int LDA = 20;                                    // floats per halo pixel in LDS (16 used)
-    constexpr int NA = (HP * 4 + 255) / 256;                   // float4 items per thread per chunk
+    constexpr int LDA = 16 * CK + 4;                           // floats per halo pixel in LDS (20 / 36: conflict-free)
+    constexpr int QS = 4 * CK;                                 // 16-byte channel quads per halo pixel per stage
+    constexpr int NA = (HP * QS + 255) / 256;                  // float4 items per thread per stage
     constexpr int A_BUF = HP * LDA + 4;                        // + one dummy 16-byte slot for padding items
     constexpr int BN = 32 * TNW;
     static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES, "winograd kernel: linear / relu / residual epilogues");
@@ -59,7 +62,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     const int y0 = ty0 * TH, x0 = tx0 * TW;
     const int n0 = nt * BN;
     const int cin = p.c0 + p.c1;
-    const int nch = cin >> 4;
+    const int nst = cin / (16 * CK);                   // stages (barriers)
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.a0, 0, (int)((((long)M - 1) * p.lda0 + p.c0) * 4), 0x00020000);
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int item = tid + 256 * i;
-        const int hp = item >> 2, c4 = item & 3;
+        const int hp = item / QS, c4 = item % QS;
         const int hy = hp / HWP, hx = hp - hy * HWP;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
         const bool ok = (hp < HP) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
@@ -82,14 +85,14 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     }
     f32x4 ra[NA], pre_sc, pre_sh;
     auto gload = [&](int c) {
-        const int ch = c * 16;
+        const int ch = c * 16 * CK;
         if (PRE) {
-            pre_sc = *(const f32x4 *)(p.pre_scale + (long)b * cin + ch + (tid & 3) * 4);
-            pre_sh = *(const f32x4 *)(p.pre_shift + (long)b * cin + ch + (tid & 3) * 4);
+            pre_sc = *(const f32x4 *)(p.pre_scale + (long)b * cin + ch + (tid % QS) * 4);
+            pre_sh = *(const f32x4 *)(p.pre_shift + (long)b * cin + ch + (tid % QS) * 4);
         }
         const bool first = ch < p.c0;
         const int ld = first ? p.lda0 : p.lda1;
-        const int chl = (first ? ch : ch - p.c0) + (tid & 3) * 4;
+        const int chl = (first ? ch : ch - p.c0) + (tid % QS) * 4;
         if (first) {
 #pragma unroll
             for (int i = 0; i < NA; ++i)
@@ -115,8 +118,8 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     // ---- fragments
     const int a_lane = ((2 * rb) * HWP + 2 * LR) * LDA + G * 4;          // patch origin of tile LR in row block rb
     const unsigned b_lane = (unsigned)(((G * p.npad) + n0 + cg * 16 * TNW + LR) * 16);   // bytes
-    auto patch_row = [&](int buf, int r, f32x4 *d) {                       // d[j] = patch(r, j), j = 0..3
-        const float *base = smem + buf * A_BUF + a_lane + r * HWP * LDA;
+    auto patch_row = [&](int buf, int sub, int r, f32x4 *d) {              // d[j] = patch(r, j), j = 0..3, 16-ch chunk `sub`
+        const float *base = smem + buf * A_BUF + a_lane + r * HWP * LDA + sub * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = *(const f32x4 *)(base + j * LDA);
     };
@@ -139,64 +142,75 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     frag_b(0, 1, fb[1]);
     lstore(0);
     __syncthreads();
-    if (nch > 1) gload(1);
+    if (nst > 1) gload(1);
     // patch rows: dA holds row 0, later row 3; dB row 2; dC row 1.  Every LDS read is issued one tap row ahead of its
     // use (row 1 under the MFMAs of tap row 0, row 3 under tap row 1, the NEXT chunk's rows 0 and 2 under tap row 3).
     f32x4 dA[4], dB[4], dC[4];
-    patch_row(0, 0, dA);
-    patch_row(0, 2, dB);
-    for (int c = 0; c < nch; ++c) {
-        const int buf = c & 1;
-        const bool more = c + 1 < nch;
+    patch_row(0, 0, 0, dA);
+    patch_row(0, 0, 2, dB);
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < nst;
 #pragma unroll
-        for (int ty = 0; ty < 4; ++ty) {
-            // B^T over the patch rows: ty 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
-            f32x4 R[4];
-            if (ty == 0) {
+        for (int sub = 0; sub < CK; ++sub) {
+            const int c = st * CK + sub;                          // 16-channel chunk index (weights)
+            const bool last_sub = sub == CK - 1;
+            const bool more_c = more || !last_sub;                // another 16-channel chunk follows
 #pragma unroll
-                for (int j = 0; j < 4; ++j) R[j] = dA[j] - dB[j];
-                patch_row(buf, 1, dC);
-            } else if (ty == 1) {
+            for (int ty = 0; ty < 4; ++ty) {
+                // B^T over the patch rows: ty 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+                f32x4 R[4];
+                if (ty == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) R[j] = dC[j] + dB[j];
-                patch_row(buf, 3, dA);
-            } else if (ty == 2) {
+                    for (int j = 0; j < 4; ++j) R[j] = dA[j] - dB[j];
+                    patch_row(buf, sub, 1, dC);
+                } else if (ty == 1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) R[j] = dB[j] - dC[j];
-            } else {
+                    for (int j = 0; j < 4; ++j) R[j] = dC[j] + dB[j];
+                    patch_row(buf, sub, 3, dA);
+                } else if (ty == 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) R[j] = dC[j] - dA[j];
-                // every LDS read of this chunk has been issued and consumed: hand the other buffer over
-                if (more) {
-                    lstore(buf ^ 1);
-                    if (c + 2 < nch) gload(c + 2);
+                    for (int j = 0; j < 4; ++j) R[j] = dB[j] - dC[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) R[j] = dC[j] - dA[j];
+                    if (last_sub) {
+                        // every LDS read of this stage has been issued and consumed: hand the other buffer over
+                        if (more) {
+                            lstore(buf ^ 1);
+                            if (st + 2 < nst) gload(st + 2);
+                        }
+                        __syncthreads();
+                        if (more) {
+                            patch_row(buf ^ 1, 0, 0, dA);
+                            patch_row(buf ^ 1, 0, 2, dB);
+                        }
+                    } else {
+                        patch_row(buf, sub + 1, 0, dA);
+                        patch_row(buf, sub + 1, 2, dB);
+                    }
                 }
-                __syncthreads();
-                if (more) {
-                    patch_row(buf ^ 1, 0, dA);
-                    patch_row(buf ^ 1, 2, dB);
+#pragma unroll
+                for (int tx = 0; tx < 4; ++tx) {
+                    const int t = ty * 4 + tx;
+                    f32x4 V;
+                    if (tx == 0) V = R[0] - R[2];
+                    else if (tx == 1) V = R[1] + R[2];
+                    else if (tx == 2) V = R[2] - R[1];
+                    else V = R[1] - R[3];
+                    if (t + 2 < 16)
+                        frag_b(c, t + 2, fb[(t + 2) & 3]);
+                    else if (more_c)
+                        frag_b(c + 1, t + 2 - 16, fb[(t + 2) & 3]);
+                    // keep the weight fetch of tap t + 2 HERE: left alone, the scheduler sinks it next to its use to
+                    // save registers and every tap then waits out an L2 round trip (seen in the ISA: load, s_waitcnt, mfma)
+                    if (SB) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < TNW; ++j)
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[e], fb[t & 3][j][e], acc[t][j], 0, 0, 0);
                 }
-            }
-#pragma unroll
-            for (int tx = 0; tx < 4; ++tx) {
-                const int t = ty * 4 + tx;
-                f32x4 V;
-                if (tx == 0) V = R[0] - R[2];
-                else if (tx == 1) V = R[1] + R[2];
-                else if (tx == 2) V = R[2] - R[1];
-                else V = R[1] - R[3];
-                if (t + 2 < 16)
-                    frag_b(c, t + 2, fb[(t + 2) & 3]);
-                else if (more)
-                    frag_b(c + 1, t + 2 - 16, fb[(t + 2) & 3]);
-                // keep the weight fetch of tap t + 2 HERE: left alone, the scheduler sinks it next to its use to save
-                // registers and every tap then waits out an L2 round trip (seen in the ISA: load, s_waitcnt, mfma)
-                if (SB) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int j = 0; j < TNW; ++j)
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[e], fb[t & 3][j][e], acc[t][j], 0, 0, 0);
             }
         }
     }

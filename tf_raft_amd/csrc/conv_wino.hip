@@ -1,21 +1,21 @@
 // Winograd F(2x2, 3x3) convolution launcher (kernel: conv_wino.h).
 #include "conv_wino.h"
 
-template <int TNW, int SB>
+template <int TNW, int SB, int CK>
 static int launch_wino(const ConvArgs &a, int epi, int grid, hipStream_t s) {
     const bool pre = a.pre_scale != nullptr, stats = a.stats != nullptr;
     if (epi == EPI_LINEAR && stats && pre)
-        conv_wino_kernel<TNW, EPI_LINEAR, 1, 1, 0><<<grid, 256, 0, s>>>(a);
+        conv_wino_kernel<TNW, EPI_LINEAR, 1, 1, 0, 1><<<grid, 256, 0, s>>>(a);
     else if (epi == EPI_LINEAR && stats)
-        conv_wino_kernel<TNW, EPI_LINEAR, 0, 1, SB><<<grid, 256, 0, s>>>(a);
+        conv_wino_kernel<TNW, EPI_LINEAR, 0, 1, SB, CK><<<grid, 256, 0, s>>>(a);
     else if (pre || stats)
         return RAFT_E_UNSUPPORTED;
     else if (epi == EPI_LINEAR)
-        conv_wino_kernel<TNW, EPI_LINEAR, 0, 0, SB><<<grid, 256, 0, s>>>(a);
+        conv_wino_kernel<TNW, EPI_LINEAR, 0, 0, SB, CK><<<grid, 256, 0, s>>>(a);
     else if (epi == EPI_RELU)
-        conv_wino_kernel<TNW, EPI_RELU, 0, 0, SB><<<grid, 256, 0, s>>>(a);
+        conv_wino_kernel<TNW, EPI_RELU, 0, 0, SB, CK><<<grid, 256, 0, s>>>(a);
     else if (epi == EPI_RES)
-        conv_wino_kernel<TNW, EPI_RES, 0, 0, SB><<<grid, 256, 0, s>>>(a);
+        conv_wino_kernel<TNW, EPI_RES, 0, 0, SB, CK><<<grid, 256, 0, s>>>(a);
     else
         return RAFT_E_UNSUPPORTED;
     return raft_launch_status();
@@ -42,6 +42,11 @@ int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s) {
     // pinned weight prefetch (SB): always at TNW = 2; at TNW = 1 only when two workgroups per CU hold the whole grid
     const char *sbe = getenv("RAFT_WINO_SB");   // tuning override: 0 / 1
     const bool sb = sbe ? atoi(sbe) != 0 : (tnw == 2 || grid <= 512);
-    if (tnw == 2) return sb ? launch_wino<2, 1>(a, epi, grid, s) : launch_wino<2, 0>(a, epi, grid, s);
-    return sb ? launch_wino<1, 1>(a, epi, grid, s) : launch_wino<1, 0>(a, epi, grid, s);
+    // 32 channels per barrier at TNW = 1 when the channel counts allow it (RAFT_WINO_CK = 1 / 2 overrides)
+    const char *cke = getenv("RAFT_WINO_CK");
+    const bool ck2_ok = a.c0 % 32 == 0 && a.c1 % 32 == 0;
+    const bool ck2 = ck2_ok && (cke ? atoi(cke) == 2 : grid <= 512);   // 58 KB of LDS: two workgroups per CU
+    if (tnw == 2) return sb ? launch_wino<2, 1, 1>(a, epi, grid, s) : launch_wino<2, 0, 1>(a, epi, grid, s);
+    if (ck2) return sb ? launch_wino<1, 1, 2>(a, epi, grid, s) : launch_wino<1, 0, 2>(a, epi, grid, s);
+    return sb ? launch_wino<1, 1, 1>(a, epi, grid, s) : launch_wino<1, 0, 1>(a, epi, grid, s);
 }

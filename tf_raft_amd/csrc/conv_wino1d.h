@@ -1,0 +1,266 @@
+// 1-D Winograd F(2, 5) for the 1x5 / 5x1 convolutions of the SepConvGRU on fp32 MFMA (v_mfma_f32_16x16x4_f32), gfx950.
+//
+// Two neighbouring outputs along the convolution axis need 6 multiplies per (input channel, output channel) instead of
+// 10 -- 1.67x fewer MACs than the direct kernel of conv_halo.h.  Interpolation points {0, +-1, +-1/2, inf}; with the
+// rows of B^T / G rescaled by powers of two (exact) the transforms are
+//
+//   B'^T d :  v0 = d0 - 5 d2 + 4 d4           G' g : u0 = g0
+//             v1 = -(d1 + d2) + 4 (d3 + d4)          u1 = (g0 + g1 + g2 + g3 + g4) / 6
+//             v2 =  (d1 - d2) - 4 (d3 - d4)          u2 = (g0 - g1 + g2 - g3 + g4) / 6
+//             v3 =  (d3 - d1) + 2 (d4 - d2)          u3 = -(4/3) g0 - (2/3) g1 - (1/3) g2 - (1/6) g3 - (1/12) g4
+//             v4 = -(d3 - d1) + 2 (d4 - d2)          u4 = -(4/3) g0 + (2/3) g1 - (1/3) g2 + (1/6) g3 - (1/12) g4
+//             v5 = d1 - 5 d3 + 4 d5                  u5 = g4 / 4
+//   A^T m  :  y0 = m0 + m1 + m2 + m3 + m4,   y1 = (m1 - m2) + (m3 - m4) / 2 + m5
+//
+// (G' g is evaluated once on the host in float64: tf_raft_amd/packing.py winograd1d_kernel).  In fp32 the result
+// deviates from the float64 convolution 1.3-1.6x as much as the direct fp32 kernel does (K = 256; tests).
+//
+//   * an MFMA row is one output PAIR; a row block is 16 pairs.  AXIS 0 (1x5): a row block = 32 consecutive pixels of
+//     one image row (pairs along x), a workgroup owns 4 rows x 32 columns; AXIS 1 (5x1): a row block = 16 consecutive
+//     columns of one row pair (pairs along y), a workgroup owns 8 rows x 16 columns.  Either way 4 row blocks x
+//     BN = 32*TNW channels; wave w -> row blocks {2 (w & 1), 2 (w & 1) + 1}, channel group w >> 1 with TNW column blocks:
+//     2 x 6 x TNW accumulators of 4 registers.  A weight fragment feeds both row blocks, a transformed input both
+//     column blocks.
+//   * K in 16-channel chunks: halo tile staged once in LDS (AXIS 0: 4 x 36 pixels at 20 floats, AXIS 1: 12 x 16 pixels
+//     at 24 floats: conflict-free ds_read_b128 for lanes stepping 2 / 1 pixels, tools/bank_check.py); a lane reads the
+//     6 inputs of its pair as b128 (4 channels), transforms them with 6 adds + 8 fmas per channel, and the four
+//     channels are the four k-steps of the tap's MFMAs.
+//   * weights: packed layout [tap][k/4][npad][4] with 6 taps, fetched from L2 two taps ahead (3-slot ring).
+//   * epilogues: the GRU gate epilogues of conv_halo.h (accumulator preload `init` becomes an addend after A^T).
+#pragma once
+#include <stdlib.h>
+
+#include "conv_mfma.h"
+
+template <int AXIS, int TNW, int EPI>
+__global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
+    constexpr int TM = 2;                                       // row blocks per wave
+    constexpr int TILE_H = AXIS == 0 ? 4 : 8, TILE_W = AXIS == 0 ? 32 : 16;
+    constexpr int HH = AXIS == 0 ? 4 : 12, HWP = AXIS == 0 ? 36 : 16, HP = HH * HWP;   // halo tile
+    constexpr int LDA = AXIS == 0 ? 20 : 24;                    // floats per halo pixel in LDS (16 used)
+    constexpr int NA = (HP * 4 + 255) / 256;
+    constexpr int A_BUF = HP * LDA + 4;
+    constexpr int BN = 32 * TNW;
+    constexpr int KSTEP = AXIS == 0 ? LDA : HWP * LDA;          // LDS floats between successive inputs of a pair
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q, "epilogue");
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int G = lane >> 4, LR = lane & 15;
+    const int rbp = w & 1, cg = w >> 1;
+    const int tiles_x = (p.W + TILE_W - 1) / TILE_W, tiles_y = (p.H + TILE_H - 1) / TILE_H;
+    const int ntn = p.npad / BN;
+    const int M = p.B * p.H * p.W;
+
+    int bid = blockIdx.x;   // XCD-aware remap (see conv_halo.h)
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = bid / ntn, nt = bid - mt * ntn;
+    const int tx0 = mt % tiles_x, ty0 = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
+    const int y0 = ty0 * TILE_H, x0 = tx0 * TILE_W;
+    const int n0 = nt * BN;
+    const int cin = p.c0 + p.c1;
+    const int nch = cin >> 4;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.a0, 0, (int)((((long)M - 1) * p.lda0 + p.c0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.c1 ? p.a1 : p.a0), 0, p.c1 ? (int)((((long)M - 1) * p.lda1 + p.c1) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.wp, 0, (int)((long)6 * cin * p.npad * 4), 0x00020000);
+
+    // ---- halo staging: item = (halo pixel, 16-byte channel quad of the chunk)
+    int pix[NA], lds_off[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int item = tid + 256 * i;
+        const int hp = item >> 2, c4 = item & 3;
+        const int hy = hp / HWP, hx = hp - hy * HWP;
+        const int yy = y0 + hy - (AXIS == 1 ? 2 : 0), xx = x0 + hx - (AXIS == 0 ? 2 : 0);
+        const bool ok = (hp < HP) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
+        pix[i] = ok ? (b * p.H + yy) * p.W + xx : -1;
+        lds_off[i] = hp < HP ? hp * LDA + c4 * 4 : HP * LDA;
+    }
+    f32x4 ra[NA];
+    auto gload = [&](int c) {
+        const int ch = c * 16;
+        const bool first = ch < p.c0;
+        const int ld = first ? p.lda0 : p.lda1;
+        const int chl = (first ? ch : ch - p.c0) + (tid & 3) * 4;
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                ra[i] = raft_buffer_load_f4(rs0, pix[i] >= 0 ? (unsigned)((pix[i] * ld + chl) * 4) : RAFT_OOB);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                ra[i] = raft_buffer_load_f4(rs1, pix[i] >= 0 ? (unsigned)((pix[i] * ld + chl) * 4) : RAFT_OOB);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *(f32x4 *)(smem + buf * A_BUF + lds_off[i]) = ra[i];
+    };
+
+    // ---- fragments.  Row block i of this wave: rb = 2 rbp + i.
+    //   AXIS 0: pair LR of image row y0 + rb: inputs at halo (rb, 2 LR + k)      AXIS 1: pair = rows (2 rb, 2 rb + 1) of
+    //   column x0 + LR: inputs at halo (2 rb + k, LR),  k = 0..5
+    auto a_lane = [&](int i) {
+        const int rb = 2 * rbp + i;
+        return (AXIS == 0 ? (rb * HWP + 2 * LR) : (2 * rb * HWP + LR)) * LDA + G * 4;
+    };
+    const unsigned b_lane = (unsigned)(((G * p.npad) + n0 + cg * 16 * TNW + LR) * 16);   // bytes
+    f32x4 fb[3][TNW];
+    auto frag_b = [&](int c, int t, f32x4 *bf) {
+        const unsigned row = (unsigned)((t * (cin >> 2) + c * 4) * p.npad) * 16u;   // wave-uniform bytes
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+            bf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(b_lane + j * 256), (int)row, 0));
+    };
+    // B'^T d for one pair, four channels at a time
+    auto transform = [&](int buf, int i, f32x4 *V) {
+        const float *base = smem + buf * A_BUF + a_lane(i);
+        f32x4 d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = *(const f32x4 *)(base + k * KSTEP);
+        const f32x4 s12 = d[1] + d[2], m12 = d[1] - d[2], s34 = d[3] + d[4], m34 = d[3] - d[4];
+        const f32x4 a = d[3] - d[1], bb = d[4] - d[2];
+        V[0] = (d[0] + 4.0f * d[4]) - 5.0f * d[2];
+        V[1] = 4.0f * s34 - s12;
+        V[2] = m12 - 4.0f * m34;
+        V[3] = a + 2.0f * bb;
+        V[4] = 2.0f * bb - a;
+        V[5] = (d[1] + 4.0f * d[5]) - 5.0f * d[3];
+    };
+
+    f32x4 acc[TM][6][TNW];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) acc[i][t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    frag_b(0, 0, fb[0]);
+    frag_b(0, 1, fb[1]);
+    lstore(0);
+    __syncthreads();
+    if (nch > 1) gload(1);
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < nch;
+        f32x4 V[TM][6];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) transform(buf, i, V[i]);
+        // every LDS read of this chunk has been issued: stage the next chunk into the other buffer
+        if (more) {
+            lstore(buf ^ 1);
+            if (c + 2 < nch) gload(c + 2);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (t + 2 < 6)
+                frag_b(c, t + 2, fb[(t + 2) % 3]);
+            else if (more)
+                frag_b(c + 1, t + 2 - 6, fb[(t + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the weight fetch two taps ahead (see conv_wino.h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j)
+                        acc[i][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[i][t][e], fb[t % 3][j][e], acc[i][t][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane owns channel n; register r of an accumulator is pair m = 4G + r of the row block
+    const int w0 = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;          // valid columns of o0
+    const int w1 = (EPI == EPI_GRU_ZR) ? p.nvalid - p.hid : 0;      // valid columns of o1
+    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + w0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(w1 > 0 ? p.o1 : p.o0), 0, w1 > 0 ? (int)((((long)M - 1) * p.ldo1 + w1) * 4) : 0, 0x00020000);
+    const bool has_e0 = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q, has_e1 = EPI == EPI_GRU_Q;
+    const int we = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;
+    const __amdgpu_buffer_rsrc_t re0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_e0 ? (const void *)p.e0 : (const void *)p.o0), 0,
+        has_e0 ? (int)((((long)M - 1) * p.lde0 + we) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t re1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_e1 ? (const void *)p.e1 : (const void *)p.o0), 0,
+        has_e1 ? (int)((((long)M - 1) * p.lde1 + we) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.init ? (const void *)p.init : (const void *)p.o0), 0,
+        p.init ? (int)((((long)M - 1) * p.ldi + p.nvalid) * 4) : 0, 0x00020000);
+    auto bstore = [](float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+    };
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+    };
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rb = 2 * rbp + i;
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const int n = n0 + (cg * TNW + j) * 16 + LR;
+            const bool nok = n < p.nvalid;
+            const float bias = p.bias[n];                         // bias has npad entries
+            const bool isz = n < p.hid;
+            const unsigned nh = (unsigned)((EPI == EPI_GRU_ZR && !isz) ? n - p.hid : n);
+            const f32x4 ya = ((acc[i][0][j] + acc[i][1][j]) + (acc[i][2][j] + acc[i][3][j])) + acc[i][4][j];
+            const f32x4 yb = ((acc[i][1][j] - acc[i][2][j]) + 0.5f * (acc[i][3][j] - acc[i][4][j])) + acc[i][5][j];
+            // pixels of the lane's 4 pairs x 2 outputs
+            unsigned mrow[4][2];
+            bool mok[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jx = 0; jx < 2; ++jx) {
+                    const int m = 4 * G + r;
+                    const int yy = AXIS == 0 ? y0 + rb : y0 + 2 * rb + jx;
+                    const int xx = AXIS == 0 ? x0 + 2 * m + jx : x0 + m;
+                    mok[r][jx] = (yy < p.H) & (xx < p.W);
+                    mrow[r][jx] = (unsigned)((b * p.H + yy) * p.W + xx);
+                }
+            float iv[4][2], hv[4][2], zv[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jx = 0; jx < 2; ++jx) {
+                    const bool ok = nok & mok[r][jx];
+                    iv[r][jx] = p.init ? bload(ri, ok ? (mrow[r][jx] * p.ldi + n) * 4u : RAFT_OOB) : 0.f;
+                    if (EPI == EPI_GRU_ZR) hv[r][jx] = bload(re0, (ok & !isz) ? (mrow[r][jx] * p.lde0 + nh) * 4u : RAFT_OOB);
+                    if (EPI == EPI_GRU_Q) {
+                        hv[r][jx] = bload(re0, ok ? (mrow[r][jx] * p.lde0 + n) * 4u : RAFT_OOB);
+                        zv[r][jx] = bload(re1, ok ? (mrow[r][jx] * p.lde1 + n) * 4u : RAFT_OOB);
+                    }
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jx = 0; jx < 2; ++jx) {
+                    const bool ok = nok & mok[r][jx];
+                    const float v = ((jx ? yb[r] : ya[r]) + iv[r][jx]) + bias;
+                    if (EPI == EPI_LINEAR || EPI == EPI_RELU) {
+                        bstore((EPI == EPI_RELU ? fmaxf(v, 0.f) : v) * p.scale, ro0, ok ? (mrow[r][jx] * p.ldo0 + n) * 4u : RAFT_OOB);
+                    } else if (EPI == EPI_GRU_ZR) {
+                        const float g = raft_sigmoid(v);
+                        bstore(g, ro0, (ok & isz) ? (mrow[r][jx] * p.ldo0 + nh) * 4u : RAFT_OOB);
+                        bstore(g * hv[r][jx], ro1, (ok & !isz) ? (mrow[r][jx] * p.ldo1 + nh) * 4u : RAFT_OOB);
+                    } else {
+                        const float q = raft_tanh(v);
+                        bstore((1.0f - zv[r][jx]) * hv[r][jx] + zv[r][jx] * q, ro0, ok ? (mrow[r][jx] * p.ldo0 + n) * 4u : RAFT_OOB);
+                    }
+                }
+        }
+    }
+}
+
+// launcher (conv_wino1d.hip): kh x kw = 1x5 or 5x1; `a.wp` holds G' g packed as a 6-tap kernel; a.init / GRU epilogues as
+// in raft_launch_conv
+int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s);

@@ -1,0 +1,39 @@
+// 1-D Winograd F(2, 5) convolution launcher (kernel: conv_wino1d.h).
+#include "conv_wino1d.h"
+
+template <int AXIS, int TNW>
+static int launch_wino1d(const ConvArgs &a, int epi, int grid, hipStream_t s) {
+    switch (epi) {
+        case EPI_LINEAR: conv_wino1d_kernel<AXIS, TNW, EPI_LINEAR><<<grid, 256, 0, s>>>(a); break;
+        case EPI_RELU: conv_wino1d_kernel<AXIS, TNW, EPI_RELU><<<grid, 256, 0, s>>>(a); break;
+        case EPI_GRU_ZR: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_ZR><<<grid, 256, 0, s>>>(a); break;
+        case EPI_GRU_Q: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_Q><<<grid, 256, 0, s>>>(a); break;
+        default: return RAFT_E_UNSUPPORTED;
+    }
+    return raft_launch_status();
+}
+
+int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s) {
+    if (!((kh == 1 && kw == 5) || (kh == 5 && kw == 1))) return RAFT_E_UNSUPPORTED;
+    if (a.c0 <= 0 || a.c0 % 16 || a.c1 < 0 || a.c1 % 16 || a.npad <= 0 || a.npad % 32) return RAFT_E_UNSUPPORTED;
+    if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
+    if (!raft_aligned16(a.a0) || !raft_aligned16(a.wp) || (a.c1 && !raft_aligned16(a.a1))) return RAFT_E_ALIGN;
+    if (a.pre_scale || a.stats || (a.Hi && (a.Hi != a.H || a.Wi != a.W))) return RAFT_E_UNSUPPORTED;
+    {   // 32-bit buffer offsets: every operand must span < 2 GiB
+        const int64_t M = (int64_t)a.B * a.H * a.W, lim = (int64_t)1 << 31;
+        if (((M - 1) * a.lda0 + a.c0) * 4 >= lim || (a.c1 && ((M - 1) * a.lda1 + a.c1) * 4 >= lim)) return RAFT_E_UNSUPPORTED;
+        if (M * a.ldo0 * 4 >= lim || (a.o1 && M * a.ldo1 * 4 >= lim) || (a.e0 && M * a.lde0 * 4 >= lim) ||
+            (a.e1 && M * a.lde1 * 4 >= lim) || (a.init && M * a.ldi * 4 >= lim))
+            return RAFT_E_UNSUPPORTED;
+        if ((int64_t)6 * (a.c0 + a.c1) * a.npad * 4 >= lim) return RAFT_E_UNSUPPORTED;
+    }
+    const int axis = kh == 5 ? 1 : 0;
+    const int tiles = axis == 0 ? a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
+    const char *e = getenv("RAFT_WINO_TNW");   // tuning / test override, read per call
+    const int forced = e ? atoi(e) : 0;
+    int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) >= 400) ? 2 : 1;
+    if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
+    const int grid = tiles * (a.npad / (32 * tnw));
+    if (axis == 0) return tnw == 2 ? launch_wino1d<0, 2>(a, epi, grid, s) : launch_wino1d<0, 1>(a, epi, grid, s);
+    return tnw == 2 ? launch_wino1d<1, 2>(a, epi, grid, s) : launch_wino1d<1, 1>(a, epi, grid, s);
+}

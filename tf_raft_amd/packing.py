@@ -67,6 +67,36 @@ def pack_conv_winograd(kernel: np.ndarray, bias: np.ndarray,
     return pack_conv(winograd_kernel(kernel), bias, sources)
 
 
+# 1-D Winograd F(2, 5), points {0, +-1, +-1/2, inf}, rows rescaled by powers of two (csrc/conv_wino1d.h): U = G' g
+_WINO1D_G = np.array([[1.0, 0.0, 0.0, 0.0, 0.0],
+                      [1 / 6, 1 / 6, 1 / 6, 1 / 6, 1 / 6],
+                      [1 / 6, -1 / 6, 1 / 6, -1 / 6, 1 / 6],
+                      [-4 / 3, -2 / 3, -1 / 3, -1 / 6, -1 / 12],
+                      [-4 / 3, 2 / 3, -1 / 3, 1 / 6, -1 / 12],
+                      [0.0, 0.0, 0.0, 0.0, 0.25]], dtype=np.float64)
+WINO1D_BT = np.array([[1, 0, -5, 0, 4, 0], [0, -1, -1, 4, 4, 0], [0, 1, -1, -4, 4, 0],
+                      [0, -1, -2, 1, 2, 0], [0, 1, -2, -1, 2, 0], [0, 1, 0, -5, 0, 4]], dtype=np.float64)
+WINO1D_AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 0.5, -0.5, 1]], dtype=np.float64)
+
+
+def winograd1d_kernel(kernel: np.ndarray) -> np.ndarray:
+    """(1, 5, Cin, Cout) or (5, 1, Cin, Cout) -> (6, 1, Cin, Cout): U[t] = sum_k G'[t, k] g[k], float64 then one rounding."""
+    k = np.asarray(kernel, dtype=np.float64)
+    if k.shape[:2] == (1, 5):
+        g = k[0]
+    elif k.shape[:2] == (5, 1):
+        g = k[:, 0]
+    else:
+        raise ValueError(f'winograd1d_kernel expects a 1x5 or 5x1 kernel, got {k.shape[:2]}')
+    return np.einsum('tk,kio->tio', _WINO1D_G, g).astype(np.float32)[:, None]
+
+
+def pack_conv_winograd1d(kernel: np.ndarray, bias: np.ndarray,
+                         sources: Sequence[Tuple[int, int]] = None) -> Tuple[np.ndarray, np.ndarray, int]:
+    """``pack_conv`` of the F(2, 5)-transformed kernel (6 taps), consumed by ``conv_wino1d_kernel``."""
+    return pack_conv(winograd1d_kernel(kernel), bias, sources)
+
+
 def fuse_n(weights: Dict[str, np.ndarray], names: Sequence[str]):
     """Concatenate several convolutions over the same input along the output-channel axis."""
     k = np.concatenate([weights[f'{n}/kernel'] for n in names], axis=3)
@@ -94,14 +124,18 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     # SepConvGRU: the `inp` rows (128:256 of hx) of z / r / q go to the loop-invariant context
     # convolution gru_ctx{s} together with the biases; the per-iteration kernels keep [h | motion | flow]
     loop_rows = np.r_[0:128, 256:384]
-    ctx = []
+    ctx, gru_w = [], []
     for s in ('1', '2'):
         k, b = fuse_n(w, [f'{p}/gru/convz{s}', f'{p}/gru/convr{s}'])
         wp, bb, npad = pack_conv(k[:, :, loop_rows, :], np.zeros_like(b), [(128, 128), (128, 128)])
         out.append((f'gru_zr{s}', wp, bb, npad))
+        wp, bb, npad = pack_conv_winograd1d(k[:, :, loop_rows, :], np.zeros_like(b), [(128, 128), (128, 128)])
+        gru_w.append((f'gru_zr{s}_w', wp, bb, npad))
         kq, bq = w[f'{p}/gru/convq{s}/kernel'], w[f'{p}/gru/convq{s}/bias']
         wp, bb, npad = pack_conv(kq[:, :, loop_rows, :], np.zeros_like(bq), [(128, 128), (128, 128)])
         out.append((f'gru_q{s}', wp, bb, npad))
+        wp, bb, npad = pack_conv_winograd1d(kq[:, :, loop_rows, :], np.zeros_like(bq), [(128, 128), (128, 128)])
+        gru_w.append((f'gru_q{s}_w', wp, bb, npad))
         kc = np.concatenate([k, kq], axis=3)[:, :, 128:256, :]
         wp, bb, npad = pack_conv(kc, np.concatenate([b, bq]))
         ctx.append((f'gru_ctx{s}', wp, bb, npad))
@@ -120,7 +154,9 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
                                 ('fh1_mask0_w', k, b, None)):
         wp, bb, npad = pack_conv_winograd(kk, bb_, src)
         out.append((field, wp, bb, npad))
-    return out
+    # F(2, 5)-transformed copies of the per-iteration SepConvGRU convolutions (field order of the C struct)
+    order = ['gru_zr1_w', 'gru_q1_w', 'gru_zr2_w', 'gru_q2_w']
+    return out + sorted(gru_w, key=lambda e: order.index(e[0]))
 
 
 def pack_small_update(weights: Dict[str, np.ndarray], prefix: str = 'update_block'):

@@ -74,5 +74,26 @@ for name, kh, kw, cin, cpad, cout in LAYERS:
             ms = e0.elapsed_time(e1) / 20
             row.append(f'wino{tnw}:{flops / ms / 1e9:6.1f}TF {ms*1e3:6.1f}us')
         os.environ.pop('RAFT_WINO_TNW', None)
+    if kh * kw == 5:             # 1-D Winograd F(2, 5) kernel
+        wpw, bw, npw = packing.pack_conv_winograd1d(k, np.zeros(cout, np.float32), [(cin, cpad)])
+        wpw_d, bw_d = _dev.to_device(wpw), _dev.to_device(bw)
+        for tnw in ('1', '2'):
+            os.environ['RAFT_WINO_TNW'] = tnw
+
+            def runw():
+                check(lib.raft_conv1d_winograd_f32(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wpw_d), _dev.ptr(bw_d), B, H, W,
+                                                   kh, kw, npw, cout, 1, 1.0, _dev.ptr(out), cout, _dev.stream_ptr()))
+            for _ in range(3):
+                runw()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                runw()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            row.append(f'wino{tnw}:{flops / ms / 1e9:6.1f}TF {ms*1e3:6.1f}us')
+        os.environ.pop('RAFT_WINO_TNW', None)
     print(f'{name:10s} K={kh*kw*cin:5d} N={cout:4d} | ' + ' | '.join(row), flush=True)
 os.environ.pop('RAFT_CONV_TILE', None)
