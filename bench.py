@@ -12,7 +12,8 @@ Inputs are generated on the device before the timed region.  With N > 1 every ra
 batch (weak scaling) and the final predictions are all-gathered over RCCL inside the timed region.
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  roofline            the dominant kernel (by accumulated time) with achieved / peak
+  roofline            the dominant kernel (by accumulated time) with achieved / peak (algorithmic FLOPs; a layer on a
+                      Winograd kernel also reports the MFMA FLOPs it really issues: executed_tflops)
   roofline_corr_lookup the HBM-bound lookup kernel the north star singles out
   stage_ms            per-kernel average milliseconds per launch (HIP events, instrumented replay)
   cpu_baseline        the CPU oracle (reference restatement, torch-CPU) timed on this box's host cores
@@ -37,6 +38,28 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.29 T
 
 STAGES = ['corr_lookup', 'convc1', 'convc2', 'convf1', 'convf2', 'conv', 'gru_zr1', 'gru_q1', 'gru_zr2',
           'gru_q2', 'fh1_mask0', 'fh2', 'mask2', 'upsample_convex']
+
+
+# Layers that run on a Winograd kernel execute fewer multiplies than the convolution they compute: F(2x2, 3x3) 16 per
+# 36 (conv_wino.h), F(2, 5) 6 per 10 (conv_wino1d.h).  `achieved` below always counts the ALGORITHMIC (direct
+# convolution) FLOPs, so it can exceed the fp32 MFMA peak; `executed_tflops` divides by this factor.
+WINOGRAD_MAC_RATIO = {'convc2': 2.25, 'conv': 2.25, 'fh1_mask0': 2.25,
+                      'gru_zr1': 10.0 / 6.0, 'gru_q1': 10.0 / 6.0, 'gru_zr2': 10.0 / 6.0, 'gru_q2': 10.0 / 6.0}
+
+
+def winograd_layers():
+    """Stage names that are on a Winograd kernel under the current RAFT_CONV_WINO / RAFT_GRU_WINO switches
+    (defaults of csrc/conv.hip: 3x3 mask 13 = convc2 | conv | fh1_mask0, GRU mask 15)."""
+    m3 = int(os.environ.get('RAFT_CONV_WINO', '13'))
+    mg = int(os.environ.get('RAFT_GRU_WINO', '15'))
+    on = set()
+    for bit, name in ((1, 'convc2'), (2, 'convf2'), (4, 'conv'), (8, 'fh1_mask0')):
+        if m3 & bit:
+            on.add(name)
+    for bit, name in ((1, 'gru_zr1'), (2, 'gru_q1'), (4, 'gru_zr2'), (8, 'gru_q2')):
+        if mg & bit:
+            on.add(name)
+    return on
 
 
 def stage_work(B, h, w):
@@ -210,6 +233,12 @@ def main():
             roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': tr,
                     'flops_per_launch': flops[dom], 'ms_per_launch': stage_ms[dom], 'traffic_source': note}
+            if dom in winograd_layers():
+                ratio = WINOGRAD_MAC_RATIO.get(dom, 2.25)
+                roof['algorithm'] = ('Winograd F(2x2,3x3)' if ratio == 2.25 else 'Winograd F(2,5)') + \
+                    ': achieved counts the direct convolution FLOPs (the algorithmic figure), executed_tflops the MFMA FLOPs issued'
+                roof['executed_tflops'] = round(ach / ratio, 2)
+                roof['frac_executed'] = round(ach / ratio / PEAK_FP32_MFMA_TFLOPS, 4)
         else:
             ach = bytes_[dom] / (stage_ms[dom] * 1e-3) / 1e9
             tr, note = traffic_of(dom)
@@ -237,6 +266,11 @@ def main():
             'note': 'fp32-MFMA GEMM: 26.5 GFLOP at B=4 bound it at >= 0.17 ms (157.3 TF), below the HBM-write bound'}
         mfma_ms = sum(stage_ms[k] for k in flops)
         result['update_block_tflops'] = round(sum(flops.values()) / (mfma_ms * 1e-3) / 1e12, 2)
+        wl = winograd_layers()
+        result['update_block_executed_tflops'] = round(
+            sum(v / (WINOGRAD_MAC_RATIO[k] if k in wl and k in WINOGRAD_MAC_RATIO else 1.0) for k, v in flops.items())
+            / (mfma_ms * 1e-3) / 1e12, 2)
+        result['winograd_layers'] = sorted(wl)
         result['stage_ms'] = stage_ms
         result['pre_loop_ms'] = {k: round(v, 4) for k, v in pre_ms.items()}
         result['roofline_timing'] = 'HIP events on the launch stream, instrumented replay of the timed steps'
