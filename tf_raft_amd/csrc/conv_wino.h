@@ -25,6 +25,10 @@
 
 #include "conv_mfma.h"
 
+#ifndef RAFT_WINO_ABL
+#define RAFT_WINO_ABL 0   // tools/ablate/wino_abl.hip builds this header with pieces of the main loop switched off
+#endif
+
 // PRE / STATS / EPI_RES serve the encoders exactly as in conv_halo.h: PRE applies relu(x * scale[b][c] + shift[b][c])
 // while the halo tile is staged (instance norm + relu of the producer), STATS writes per-(workgroup, row block)
 // (sum, sum of squares) of the raw output per channel [2 * pixel tile + rb][npad][2], EPI_RES is the ResBlock tail.
@@ -119,6 +123,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     const int a_lane = ((2 * rb) * HWP + 2 * LR) * LDA + G * 4;          // patch origin of tile LR in row block rb
     const unsigned b_lane = (unsigned)(((G * p.npad) + n0 + cg * 16 * TNW + LR) * 16);   // bytes
     auto patch_row = [&](int buf, int sub, int r, f32x4 *d) {              // d[j] = patch(r, j), j = 0..3, 16-ch chunk `sub`
+        if ((RAFT_WINO_ABL & 2) && !(buf == 0 && sub == 0 && r != 1 && r != 3)) return;
         const float *base = smem + buf * A_BUF + a_lane + r * HWP * LDA + sub * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = *(const f32x4 *)(base + j * LDA);
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                     for (int j = 0; j < 4; ++j) R[j] = dC[j] - dA[j];
                     if (last_sub) {
                         // every LDS read of this stage has been issued and consumed: hand the other buffer over
-                        if (more) {
+                        if (more && !(RAFT_WINO_ABL & 4)) {
                             lstore(buf ^ 1);
                             if (st + 2 < nst) gload(st + 2);
                         }
@@ -194,14 +199,17 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                 for (int tx = 0; tx < 4; ++tx) {
                     const int t = ty * 4 + tx;
                     f32x4 V;
-                    if (tx == 0) V = R[0] - R[2];
+                    if (RAFT_WINO_ABL & 16) V = R[tx];
+                    else if (tx == 0) V = R[0] - R[2];
                     else if (tx == 1) V = R[1] + R[2];
                     else if (tx == 2) V = R[2] - R[1];
                     else V = R[1] - R[3];
-                    if (t + 2 < 16)
-                        frag_b(c, t + 2, fb[(t + 2) & 3]);
-                    else if (more_c)
-                        frag_b(c + 1, t + 2 - 16, fb[(t + 2) & 3]);
+                    if (!(RAFT_WINO_ABL & 1)) {
+                        if (t + 2 < 16)
+                            frag_b(c, t + 2, fb[(t + 2) & 3]);
+                        else if (more_c)
+                            frag_b(c + 1, t + 2 - 16, fb[(t + 2) & 3]);
+                    }
                     // keep the weight fetch of tap t + 2 HERE: left alone, the scheduler sinks it next to its use to
                     // save registers and every tap then waits out an L2 round trip (seen in the ISA: load, s_waitcnt, mfma)
                     if (SB) __builtin_amdgcn_sched_barrier(0);
@@ -269,6 +277,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                         s2 = fmaf(v, v, s2);
                     }
                     const unsigned m = (unsigned)((b * p.H + yy) * p.W + xx + jx);
+                    if ((RAFT_WINO_ABL & 8) && v != 12345.678f) continue;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro0,
                                                           (nok & mok) ? (int)((m * p.ldo0 + n) * 4u) : (int)RAFT_OOB, 0, 0);
                 }
