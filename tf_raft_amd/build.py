@@ -41,7 +41,20 @@ def _digest(paths):
 
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
+    """Build (or reuse) the library.  Safe against concurrent callers -- e.g. the 8 ranks of a multi-GPU launch on a box
+    without a prebuilt .so: an inter-process file lock serialises them, the first builds, the others reuse; the shared
+    object is linked under a temporary name and renamed into place."""
+    import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     stamp = os.path.join(LIBDIR, 'build.sha256')
@@ -63,10 +76,12 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIBPATH]
+    tmp = LIBPATH + f'.tmp{os.getpid()}'
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', tmp]
     if verbose:
         print('[build]', ' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    os.replace(tmp, LIBPATH)
     with open(stamp, 'w') as f:
         f.write(digest)
     return LIBPATH
