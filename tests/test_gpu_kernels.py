@@ -267,14 +267,18 @@ def test_conv2d_mfma_matches_oracle(rng, ksize, tile):
     assert err < 2e-5
 
 
-@pytest.mark.parametrize('tnw', ['1', '2'])
+# kernel variants: channel blocks of 32 / 64 (TNW), pinned weight prefetch on / off (SB), 16 / 32 channels per barrier (CK)
+@pytest.mark.parametrize('variant', ['tnw1', 'tnw2', 'tnw1-sb0-ck1', 'tnw1-sb0-ck2', 'tnw1-sb1-ck1', 'tnw2-sb0'])
 @pytest.mark.parametrize('shape', [(2, 9, 13), (1, 8, 64), (1, 5, 35)])      # ragged tiles, exact tiles, 2 x-tiles + tail
-def test_conv2d_winograd_matches_oracle(rng, shape, tnw, monkeypatch):
+def test_conv2d_winograd_matches_oracle(rng, shape, variant, monkeypatch):
     """Winograd F(2x2, 3x3) kernel (conv_wino.h) against the float64 direct convolution; two sources, N tail."""
     from oracle import tf_ops
     from tf_raft_amd import _dev, packing
     from tf_raft_amd._ffi import check
-    monkeypatch.setenv('RAFT_WINO_TNW', tnw)
+    for part in variant.split('-'):
+        key = {'tnw': 'RAFT_WINO_TNW', 'sb': 'RAFT_WINO_SB', 'ck': 'RAFT_WINO_CK'}[part.rstrip('012')]
+        monkeypatch.setenv(key, part[-1])
+    tnw = variant
     B, H, W = shape
     c_a, c_b, cout = 40, 64, 150
     xa = rng.normal(size=(B, H, W, c_a)).astype(np.float32)
@@ -282,17 +286,19 @@ def test_conv2d_winograd_matches_oracle(rng, shape, tnw, monkeypatch):
     kernel = (rng.normal(size=(3, 3, c_a + c_b, cout)) * 0.1).astype(np.float32)
     bias = rng.normal(size=(cout,)).astype(np.float32)
     srcs = []
-    for arr, cpad in ((xa, 48), (xb, 64)):                     # the winograd kernel walks 16-channel chunks
+    pad_a = 64 if 'ck2' in variant else 48                     # 32 channels per barrier need sources in multiples of 32
+    for arr, cpad in ((xa, pad_a), (xb, 64)):                  # the winograd kernel walks 16-channel chunks
         buf = np.zeros((B, H, W, cpad), np.float32)
         buf[..., :arr.shape[-1]] = arr
         srcs.append(_dev.to_device(buf))
-    # pack_conv pads sources to multiples of 32: pad 40 -> 64 rows, of which the kernel walks the first 48
+    # pack_conv pads sources to multiples of 32: pad 40 -> 64 rows, of which the kernel walks the first pad_a
     wp, b, npad = packing.pack_conv_winograd(kernel, bias, [(c_a, 64), (c_b, 64)])
     assert wp.shape == (16, 32, npad, 4)
-    wp = np.ascontiguousarray(np.concatenate([wp[:, :12], wp[:, 16:]], axis=1))      # drop the 16 all-zero rows 48..63
+    if pad_a == 48:
+        wp = np.ascontiguousarray(np.concatenate([wp[:, :12], wp[:, 16:]], axis=1))  # drop the 16 all-zero rows 48..63
     wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
     out = torch.full((B, H, W, cout), float('nan'), device=srcs[0].device)
-    check(_dev.lib().raft_conv2d_winograd_f32(_dev.ptr(srcs[0]), 48, 48, _dev.ptr(srcs[1]), 64, 64, _dev.ptr(wp_d),
+    check(_dev.lib().raft_conv2d_winograd_f32(_dev.ptr(srcs[0]), pad_a, pad_a, _dev.ptr(srcs[1]), 64, 64, _dev.ptr(wp_d),
                                               _dev.ptr(b_d), B, H, W, npad, cout, 1, 0.5, _dev.ptr(out), cout,
                                               _dev.stream_ptr()), 'conv2d_winograd')
     torch.cuda.synchronize()
