@@ -312,7 +312,7 @@ def test_conv2d_winograd_matches_oracle(rng, shape, variant, monkeypatch):
     assert err < 2e-5
 
 
-@pytest.mark.parametrize('tnw', ['1', '2'])
+@pytest.mark.parametrize('tnw', ['1', '2', '1-ck2', '2-ck2'])
 @pytest.mark.parametrize('ksize', [(1, 5), (5, 1)])
 @pytest.mark.parametrize('shape', [(2, 9, 13), (1, 8, 64), (1, 21, 35)])
 def test_conv1d_winograd_matches_oracle(rng, shape, ksize, tnw, monkeypatch):
@@ -320,10 +320,11 @@ def test_conv1d_winograd_matches_oracle(rng, shape, ksize, tnw, monkeypatch):
     from oracle import tf_ops
     from tf_raft_amd import _dev, packing
     from tf_raft_amd._ffi import check
-    monkeypatch.setenv('RAFT_WINO_TNW', tnw)
+    monkeypatch.setenv('RAFT_WINO_TNW', tnw[0])
+    monkeypatch.setenv('RAFT_WINO_CK', '2' if 'ck2' in tnw else '1')
     kh, kw = ksize
     B, H, W = shape
-    c_a, c_b, cout = 48, 64, 150
+    c_a, c_b, cout = (64 if 'ck2' in tnw else 48), 64, 150          # 32 channels per barrier: sources in multiples of 32
     xa = rng.normal(size=(B, H, W, c_a)).astype(np.float32)
     xb = rng.normal(size=(B, H, W, c_b)).astype(np.float32)
     kernel = (rng.normal(size=(kh, kw, c_a + c_b, cout)) * 0.1).astype(np.float32)
@@ -331,7 +332,8 @@ def test_conv1d_winograd_matches_oracle(rng, shape, ksize, tnw, monkeypatch):
     sa, sb = _dev.to_device(xa), _dev.to_device(xb)
     wp, b, npad = packing.pack_conv_winograd1d(kernel, bias, [(c_a, 64), (c_b, 64)])
     assert wp.shape == (6, 32, npad, 4)
-    wp = np.ascontiguousarray(np.concatenate([wp[:, :12], wp[:, 16:]], axis=1))      # drop the all-zero rows 48..63
+    if c_a == 48:
+        wp = np.ascontiguousarray(np.concatenate([wp[:, :12], wp[:, 16:]], axis=1))  # drop the all-zero rows 48..63
     wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
     out = torch.full((B, H, W, cout), float('nan'), device=sa.device)
     check(_dev.lib().raft_conv1d_winograd_f32(_dev.ptr(sa), c_a, c_a, _dev.ptr(sb), c_b, c_b, _dev.ptr(wp_d), _dev.ptr(b_d),

@@ -32,13 +32,15 @@
 
 #include "conv_mfma.h"
 
-template <int AXIS, int TNW, int EPI>
+// CK = 16-channel chunks staged per barrier (1 or 2).
+template <int AXIS, int TNW, int EPI, int CK = 1>
 __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
     constexpr int TM = 2;                                       // row blocks per wave
     constexpr int TILE_H = AXIS == 0 ? 4 : 8, TILE_W = AXIS == 0 ? 32 : 16;
     constexpr int HH = AXIS == 0 ? 4 : 12, HWP = AXIS == 0 ? 36 : 16, HP = HH * HWP;   // halo tile
-    constexpr int LDA = AXIS == 0 ? 20 : 24;                    // floats per halo pixel in LDS (16 used)
-    constexpr int NA = (HP * 4 + 255) / 256;
+    constexpr int LDA = AXIS == 0 ? (CK == 1 ? 20 : 36) : (CK == 1 ? 24 : 40);   // floats per halo pixel in LDS
+    constexpr int QS = 4 * CK;                                  // 16-byte channel quads per halo pixel per stage
+    constexpr int NA = (HP * QS + 255) / 256;
     constexpr int A_BUF = HP * LDA + 4;
     constexpr int BN = 32 * TNW;
     constexpr int KSTEP = AXIS == 0 ? LDA : HWP * LDA;          // LDS floats between successive inputs of a pair
@@ -62,7 +64,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
     const int y0 = ty0 * TILE_H, x0 = tx0 * TILE_W;
     const int n0 = nt * BN;
     const int cin = p.c0 + p.c1;
-    const int nch = cin >> 4;
+    const int nst = cin / (16 * CK);                            // stages (barriers)
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.a0, 0, (int)((((long)M - 1) * p.lda0 + p.c0) * 4), 0x00020000);
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int item = tid + 256 * i;
-        const int hp = item >> 2, c4 = item & 3;
+        const int hp = item / QS, c4 = item % QS;
         const int hy = hp / HWP, hx = hp - hy * HWP;
         const int yy = y0 + hy - (AXIS == 1 ? 2 : 0), xx = x0 + hx - (AXIS == 0 ? 2 : 0);
         const bool ok = (hp < HP) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
@@ -85,10 +87,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
     }
     f32x4 ra[NA];
     auto gload = [&](int c) {
-        const int ch = c * 16;
+        const int ch = c * 16 * CK;
         const bool first = ch < p.c0;
         const int ld = first ? p.lda0 : p.lda1;
-        const int chl = (first ? ch : ch - p.c0) + (tid & 3) * 4;
+        const int chl = (first ? ch : ch - p.c0) + (tid % QS) * 4;
         if (first) {
 #pragma unroll
             for (int i = 0; i < NA; ++i)
@@ -120,8 +122,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
             bf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(b_lane + j * 256), (int)row, 0));
     };
     // B'^T d for one pair, four channels at a time
-    auto transform = [&](int buf, int i, f32x4 *V) {
-        const float *base = smem + buf * A_BUF + a_lane(i);
+    auto transform = [&](int buf, int sub, int i, f32x4 *V) {
+        const float *base = smem + buf * A_BUF + a_lane(i) + sub * 16;
         f32x4 d[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) d[k] = *(const f32x4 *)(base + k * KSTEP);
@@ -148,33 +150,40 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
     frag_b(0, 1, fb[1]);
     lstore(0);
     __syncthreads();
-    if (nch > 1) gload(1);
-    for (int c = 0; c < nch; ++c) {
-        const int buf = c & 1;
-        const bool more = c + 1 < nch;
-        f32x4 V[TM][6];
+    if (nst > 1) gload(1);
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < nst;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) transform(buf, i, V[i]);
-        // every LDS read of this chunk has been issued: stage the next chunk into the other buffer
-        if (more) {
-            lstore(buf ^ 1);
-            if (c + 2 < nch) gload(c + 2);
-        }
-        __syncthreads();
+        for (int sub = 0; sub < CK; ++sub) {
+            const int c = st * CK + sub;                          // 16-channel chunk index (weights)
+            const bool more_c = more || sub + 1 < CK;
+            f32x4 V[TM][6];
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            if (t + 2 < 6)
-                frag_b(c, t + 2, fb[(t + 2) % 3]);
-            else if (more)
-                frag_b(c + 1, t + 2 - 6, fb[(t + 2) % 3]);
-            __builtin_amdgcn_sched_barrier(0);   // keep the weight fetch two taps ahead (see conv_wino.h)
+            for (int i = 0; i < TM; ++i) transform(buf, sub, i, V[i]);
+            if (sub == CK - 1) {
+                // every LDS read of this stage has been issued: stage the next one into the other buffer
+                if (more) {
+                    lstore(buf ^ 1);
+                    if (st + 2 < nst) gload(st + 2);
+                }
+                __syncthreads();
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int t = 0; t < 6; ++t) {
+                if (t + 2 < 6)
+                    frag_b(c, t + 2, fb[(t + 2) % 3]);
+                else if (more_c)
+                    frag_b(c + 1, t + 2 - 6, fb[(t + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);   // keep the weight fetch two taps ahead (see conv_wino.h)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < TNW; ++j)
-                        acc[i][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[i][t][e], fb[t % 3][j][e], acc[i][t][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNW; ++j)
+                            acc[i][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[i][t][e], fb[t % 3][j][e], acc[i][t][j], 0, 0, 0);
+            }
         }
     }
 

@@ -1,13 +1,15 @@
 // 1-D Winograd F(2, 5) convolution launcher (kernel: conv_wino1d.h).
 #include "conv_wino1d.h"
 
-template <int AXIS, int TNW>
+constexpr bool RAFT_WINO1D_CK2_DEFAULT = true;   // 32 channels per barrier: +2-4 % on the GRU layers (profiles/r03u)
+
+template <int AXIS, int TNW, int CK>
 static int launch_wino1d(const ConvArgs &a, int epi, int grid, hipStream_t s) {
     switch (epi) {
-        case EPI_LINEAR: conv_wino1d_kernel<AXIS, TNW, EPI_LINEAR><<<grid, 256, 0, s>>>(a); break;
-        case EPI_RELU: conv_wino1d_kernel<AXIS, TNW, EPI_RELU><<<grid, 256, 0, s>>>(a); break;
-        case EPI_GRU_ZR: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_ZR><<<grid, 256, 0, s>>>(a); break;
-        case EPI_GRU_Q: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_Q><<<grid, 256, 0, s>>>(a); break;
+        case EPI_LINEAR: conv_wino1d_kernel<AXIS, TNW, EPI_LINEAR, CK><<<grid, 256, 0, s>>>(a); break;
+        case EPI_RELU: conv_wino1d_kernel<AXIS, TNW, EPI_RELU, CK><<<grid, 256, 0, s>>>(a); break;
+        case EPI_GRU_ZR: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_ZR, CK><<<grid, 256, 0, s>>>(a); break;
+        case EPI_GRU_Q: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_Q, CK><<<grid, 256, 0, s>>>(a); break;
         default: return RAFT_E_UNSUPPORTED;
     }
     return raft_launch_status();
@@ -31,9 +33,18 @@ int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStrea
     const int tiles = axis == 0 ? a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
     const char *e = getenv("RAFT_WINO_TNW");   // tuning / test override, read per call
     const int forced = e ? atoi(e) : 0;
-    int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) >= 400) ? 2 : 1;
+    // 64-channel workgroups (a transformed input feeds two column blocks) beat 32-channel ones even when they leave
+    // under one workgroup per CU (gru_q at B = 4: 224 workgroups, 33.9 vs 36.0 us)
+    int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) >= 200) ? 2 : 1;
     if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
     const int grid = tiles * (a.npad / (32 * tnw));
-    if (axis == 0) return tnw == 2 ? launch_wino1d<0, 2>(a, epi, grid, s) : launch_wino1d<0, 1>(a, epi, grid, s);
-    return tnw == 2 ? launch_wino1d<1, 2>(a, epi, grid, s) : launch_wino1d<1, 1>(a, epi, grid, s);
+    // 32 channels per barrier when the channel counts allow it (RAFT_WINO_CK = 1 / 2 overrides)
+    const char *cke = getenv("RAFT_WINO_CK");
+    const bool ck2 = a.c0 % 32 == 0 && a.c1 % 32 == 0 && (cke ? atoi(cke) == 2 : RAFT_WINO1D_CK2_DEFAULT);
+    if (axis == 0) {
+        if (ck2) return tnw == 2 ? launch_wino1d<0, 2, 2>(a, epi, grid, s) : launch_wino1d<0, 1, 2>(a, epi, grid, s);
+        return tnw == 2 ? launch_wino1d<0, 2, 1>(a, epi, grid, s) : launch_wino1d<0, 1, 1>(a, epi, grid, s);
+    }
+    if (ck2) return tnw == 2 ? launch_wino1d<1, 2, 2>(a, epi, grid, s) : launch_wino1d<1, 1, 2>(a, epi, grid, s);
+    return tnw == 2 ? launch_wino1d<1, 2, 1>(a, epi, grid, s) : launch_wino1d<1, 1, 1>(a, epi, grid, s);
 }
