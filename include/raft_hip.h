@@ -289,6 +289,8 @@ int raft_encoder_f32(const raft_encoder_weights *w, const float *images, int n, 
  * + 28 zero pad; mask is unused (SmallUpdateBlock returns None). */
 typedef struct raft_small_update_weights {
     raft_conv_weights convc1, convf1, convf2, conv, gru_zr, gru_q, fh1, fh2;
+    /* optional: Winograd F(2x2, 3x3) transformed copies of the 3x3 layers (see raft_basic_update_weights) */
+    raft_conv_weights conv_w, gru_zr_w, gru_q_w, fh1_w;
 } raft_small_update_weights;
 
 int64_t raft_small_update_workspace_floats(int B, int h, int w);

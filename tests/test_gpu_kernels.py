@@ -368,6 +368,26 @@ def test_basic_update_block_winograd_gru_matches_direct(rng, monkeypatch):
         assert np.abs(wn - dn).max() > 0
 
 
+def test_small_update_block_winograd_layers_match_direct(rng, monkeypatch):
+    """RAFT_SMALL_WINO=15: conv, the 3x3 ConvGRU (gate epilogues of conv_wino.h) and flow_head.conv1 of SmallRAFT."""
+    from tf_raft_amd import weights as wm
+    from tf_raft_amd.layers.update import SmallUpdateBlock
+    wts = wm.init_weights('small', seed=3, perturb=True)
+    for shape in ((1, 56, 64), (2, 9, 13)):
+        net, inp, corr, flow = _update_inputs(rng, 'small', *shape)
+        blk = SmallUpdateBlock(filters=96, weights=wts)
+        monkeypatch.setenv('RAFT_SMALL_WINO', '0')
+        dn, _, dd = blk([net, inp, corr, flow])
+        dn, dd = _np(dn), _np(dd)
+        monkeypatch.setenv('RAFT_SMALL_WINO', '15')
+        wn, _, wd = blk([net, inp, corr, flow])
+        wn, wd = _np(wn), _np(wd)
+        report(f'small update block winograd vs direct {shape}', net=float(np.abs(wn - dn).max()),
+               delta=float(np.abs(wd - dd).max()))
+        assert np.abs(wn - dn).max() < 2e-5 and np.abs(wd - dd).max() < 5e-5
+        assert np.abs(wn - dn).max() > 0
+
+
 def test_basic_update_block_winograd_layers_match_direct(rng, monkeypatch):
     """RAFT_CONV_WINO=15: all four 3x3 layers of the update block on the winograd kernel."""
     from tf_raft_amd import weights as wm

@@ -32,7 +32,8 @@ class BasicUpdateWeights(C.Structure):
 
 class SmallUpdateWeights(C.Structure):
     _fields_ = [(n, ConvWeights) for n in (
-        'convc1', 'convf1', 'convf2', 'conv', 'gru_zr', 'gru_q', 'fh1', 'fh2')]
+        'convc1', 'convf1', 'convf2', 'conv', 'gru_zr', 'gru_q', 'fh1', 'fh2',
+        'conv_w', 'gru_zr_w', 'gru_q_w', 'fh1_w')]
 
 
 class EncoderWeights(C.Structure):

@@ -232,10 +232,11 @@ static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weig
 // {1: convc2, 2: convf2, 4: conv, 8: fh1_mask0}; unset = RAFT_WINO_DEFAULT (the layers where it measured faster at
 // B = 4).  Read per call so that tests can switch it.
 constexpr int RAFT_WINO_DEFAULT = 13;
+constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr, 4: gru_q, 8: fh1}, switch RAFT_SMALL_WINO
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
-                          hipStream_t s) {
-    const char *e = getenv("RAFT_CONV_WINO");
-    const int mask = e ? atoi(e) : RAFT_WINO_DEFAULT;
+                          hipStream_t s, bool small = false) {
+    const char *e = getenv(small ? "RAFT_SMALL_WINO" : "RAFT_CONV_WINO");
+    const int mask = e ? atoi(e) : (small ? RAFT_SMALL_WINO_DEFAULT : RAFT_WINO_DEFAULT);
     if ((mask & bit) && wino.wp != nullptr) {
         a.wp = wino.wp;
         a.bias = wino.bias;
@@ -810,22 +811,22 @@ extern "C" int raft_update_small_f32(const raft_small_update_weights *wts, int B
     }
     {   // out = relu(conv(cat[cor, flo])) 3x3, 128 -> 80        -> x[:, 64:144]
         ConvArgs a = conv_args(wts->conv, corflo, 128, 128, nullptr, 0, 0, B, h, w, 80, st->x + 64, S_XLD);
-        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+        RAFT_TRY(launch_conv3x3(wts->conv, wts->conv_w, 1, a, EPI_RELU, s, true));
     }
     {   // ConvGRU (update.py:26-35), 3x3: z | r
         ConvArgs a = conv_args(wts->gru_zr, st->net, S_HDIM, S_HDIM, st->x, S_XLD, S_XLD, B, h, w, 2 * S_HDIM, zb,
                                S_HDIM);
         a.hid = S_HDIM; a.o1 = rh; a.ldo1 = S_HDIM; a.e0 = st->net; a.lde0 = S_HDIM;
-        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_GRU_ZR, s));
+        RAFT_TRY(launch_conv3x3(wts->gru_zr, wts->gru_zr_w, 2, a, EPI_GRU_ZR, s, true));
     }
     {
         ConvArgs a = conv_args(wts->gru_q, rh, S_HDIM, S_HDIM, st->x, S_XLD, S_XLD, B, h, w, S_HDIM, st->net, S_HDIM);
         a.e0 = st->net; a.lde0 = S_HDIM; a.e1 = zb; a.lde1 = S_HDIM;
-        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_GRU_Q, s));
+        RAFT_TRY(launch_conv3x3(wts->gru_q, wts->gru_q_w, 4, a, EPI_GRU_Q, s, true));
     }
     {   // relu(flow_head.conv1(net))    3x3, 96 -> 128
         ConvArgs a = conv_args(wts->fh1, st->net, S_HDIM, S_HDIM, nullptr, 0, 0, B, h, w, 128, fh, 128);
-        RAFT_TRY(raft_launch_conv(a, 3, 3, EPI_RELU, s));
+        RAFT_TRY(launch_conv3x3(wts->fh1, wts->fh1_w, 8, a, EPI_RELU, s, true));
     }
     {   // delta = flow_head.conv2(.), coords1 += delta, flow = coords1 - coords0
         flowhead2_kernel<128><<<raft_ceil_div((int64_t)B * h * ((w + 3) / 4), 4), 256, 0, s>>>(fh, 128, wts->fh2.wp, wts->fh2.bias, B, h, w,

@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     constexpr int NA = (HP * QS + 255) / 256;                  // float4 items per thread per stage
     constexpr int A_BUF = HP * LDA + 4;                        // + one dummy 16-byte slot for padding items
     constexpr int BN = 32 * TNW;
-    static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES, "winograd kernel: linear / relu / residual epilogues");
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q,
+                  "winograd kernel: linear / relu / residual / GRU gate epilogues");
     __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -224,16 +225,29 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     }
 
     // ---- epilogue: lane owns channel n; register r of an accumulator is tile m = 4G + r of the row block
+    // GRU gates (the 3x3 ConvGRU of SmallRAFT, reference update.py:17-35) as in conv_halo.h: GRU_ZR writes z to o0 and
+    // r * h to o1 (h = e0), GRU_Q writes (1 - z) h + z tanh(.) (h = e0, z = e1)
+    constexpr bool GRU = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q, HAS_E0 = EPI == EPI_RES || GRU;
+    const int w0 = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;          // valid columns of o0
+    const int w1 = (EPI == EPI_GRU_ZR) ? p.nvalid - p.hid : 0;      // valid columns of o1
+    const int we = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;
     const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + p.nvalid) * 4), 0x00020000);
+        (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + w0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(w1 > 0 ? p.o1 : p.o0), 0, w1 > 0 ? (int)((((long)M - 1) * p.ldo1 + w1) * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t re0 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(EPI == EPI_RES ? (const void *)p.e0 : (const void *)p.o0), 0,
-        EPI == EPI_RES ? (int)((((long)M - 1) * p.lde0 + p.nvalid) * 4) : 0, 0x00020000);
+        (void *)(HAS_E0 ? (const void *)p.e0 : (const void *)p.o0), 0,
+        HAS_E0 ? (int)((((long)M - 1) * p.lde0 + we) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t re1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(EPI == EPI_GRU_Q ? (const void *)p.e1 : (const void *)p.o0), 0,
+        EPI == EPI_GRU_Q ? (int)((((long)M - 1) * p.lde1 + we) * 4) : 0, 0x00020000);
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
         const int n = n0 + (cg * TNW + j) * 16 + LR;
         const bool nok = n < p.nvalid;
         const float bias = p.bias[n];                         // bias has npad entries
+        const bool isz = n < p.hid;
+        const unsigned nh = (unsigned)((EPI == EPI_GRU_ZR && !isz) ? n - p.hid : n);
         float s1 = 0.f, s2 = 0.f;
         // A^T over the tap rows: T[i][tx], i = 0: M0 + M1 + M2, i = 1: M1 - M2 - M3
         f32x4 T[2][4];
@@ -246,17 +260,20 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
         for (int i = 0; i < 2; ++i) {
             const f32x4 ya = (T[i][0] + T[i][1]) + T[i][2], yb = (T[i][1] - T[i][2]) - T[i][3];
             const int yy = y0 + 2 * rb + i;
-            float xv[4][2];
-            if (EPI == EPI_RES) {
+            float xv[4][2], zv[4][2];
+            if (HAS_E0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int jx = 0; jx < 2; ++jx) {
                         const int xx = x0 + 2 * (4 * G + r) + jx;
-                        const bool ok = nok & (yy < p.H) & (xx < p.W);
+                        const bool ok = nok & (yy < p.H) & (xx < p.W) & !(EPI == EPI_GRU_ZR && isz);
                         const unsigned m = (unsigned)((b * p.H + yy) * p.W + xx);
                         xv[r][jx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                                  re0, ok ? (int)((m * p.lde0 + n) * 4u) : (int)RAFT_OOB, 0, 0));
+                                                                  re0, ok ? (int)((m * p.lde0 + nh) * 4u) : (int)RAFT_OOB, 0, 0));
+                        if (EPI == EPI_GRU_Q)
+                            zv[r][jx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                      re1, ok ? (int)((m * p.lde1 + n) * 4u) : (int)RAFT_OOB, 0, 0));
                     }
             }
 #pragma unroll
@@ -266,7 +283,19 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                 for (int jx = 0; jx < 2; ++jx) {
                     float v = (jx ? yb[r] : ya[r]) + bias;
                     const bool mok = (yy < p.H) & (xx + jx < p.W);
-                    if (EPI == EPI_RES) {
+                    const unsigned mg = (unsigned)((b * p.H + yy) * p.W + xx + jx);
+                    if (EPI == EPI_GRU_ZR) {
+                        const float g = raft_sigmoid(v);
+                        const bool ok = nok & mok;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), ro0,
+                                                              (ok & isz) ? (int)((mg * p.ldo0 + nh) * 4u) : (int)RAFT_OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g * xv[r][jx]), ro1,
+                                                              (ok & !isz) ? (int)((mg * p.ldo1 + nh) * 4u) : (int)RAFT_OOB, 0, 0);
+                        continue;
+                    }
+                    if (EPI == EPI_GRU_Q) {
+                        v = (1.0f - zv[r][jx]) * xv[r][jx] + zv[r][jx] * raft_tanh(v);
+                    } else if (EPI == EPI_RES) {
                         v = fmaxf(xv[r][jx] + fmaxf(v, 0.f), 0.f);
                     } else {
                         if (EPI == EPI_RELU) v = fmaxf(v, 0.f);

@@ -16,6 +16,10 @@ static int launch_wino(const ConvArgs &a, int epi, int grid, hipStream_t s) {
         conv_wino_kernel<TNW, EPI_RELU, 0, 0, SB, CK><<<grid, 256, 0, s>>>(a);
     else if (epi == EPI_RES)
         conv_wino_kernel<TNW, EPI_RES, 0, 0, SB, CK><<<grid, 256, 0, s>>>(a);
+    else if (epi == EPI_GRU_ZR)
+        conv_wino_kernel<TNW, EPI_GRU_ZR, 0, 0, SB, CK><<<grid, 256, 0, s>>>(a);
+    else if (epi == EPI_GRU_Q)
+        conv_wino_kernel<TNW, EPI_GRU_Q, 0, 0, SB, CK><<<grid, 256, 0, s>>>(a);
     else
         return RAFT_E_UNSUPPORTED;
     return raft_launch_status();
@@ -26,6 +30,7 @@ int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s) {
     if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
     if (!raft_aligned16(a.a0) || !raft_aligned16(a.wp) || (a.c1 && !raft_aligned16(a.a1))) return RAFT_E_ALIGN;
     if (a.init || (a.Hi && (a.Hi != a.H || a.Wi != a.W))) return RAFT_E_UNSUPPORTED;
+    if ((epi == EPI_GRU_ZR || epi == EPI_GRU_Q) && (a.e0 == nullptr || (epi == EPI_GRU_Q && a.e1 == nullptr))) return RAFT_E_NULL;
     if (epi == EPI_RES && (a.e0 == nullptr || (int64_t)a.B * a.H * a.W * a.lde0 * 4 >= ((int64_t)1 << 31))) return RAFT_E_UNSUPPORTED;
     {   // 32-bit buffer offsets: every operand must span < 2 GiB
         const int64_t M = (int64_t)a.B * a.H * a.W, lim = (int64_t)1 << 31;

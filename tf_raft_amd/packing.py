@@ -183,6 +183,13 @@ def pack_small_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     conv('fh1', f'{p}/flow_head/conv1')
     out.append(('fh2', np.ascontiguousarray(w[f'{p}/flow_head/conv2/kernel'], dtype=np.float32).reshape(9, 128, 2),
                 np.asarray(w[f'{p}/flow_head/conv2/bias'], dtype=np.float32), 2))
+    # Winograd F(2x2, 3x3) copies of the 3x3 layers (field order of raft_small_update_weights)
+    for field, kk, bb_, src in (('conv_w', w[f'{p}/encoder/conv/kernel'], w[f'{p}/encoder/conv/bias'], None),
+                                ('gru_zr_w', k, b, [(96, 96), (146, 160)]),
+                                ('gru_q_w', w[f'{p}/gru/convq/kernel'], w[f'{p}/gru/convq/bias'], [(96, 96), (146, 160)]),
+                                ('fh1_w', w[f'{p}/flow_head/conv1/kernel'], w[f'{p}/flow_head/conv1/bias'], None)):
+        wp, bb, npad = pack_conv_winograd(kk, bb_, src)
+        out.append((field, wp, bb, npad))
     return out
 
 
