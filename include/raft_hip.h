@@ -236,6 +236,12 @@ int raft_iterate_basic_overlap_f32(const raft_basic_update_weights *wts, const f
                                    const int64_t *level_offsets, int B, int h, int w, int iters,
                                    const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1);
 
+/* The three-stream loop with the volume-free correlation (BASELINE config 4, no reference code: README.md:109):
+ * fmap1 (B, h, w, C) and fmap2_pyr (raft_fmap_pyramid_f32) replace the stored pyramid. */
+int raft_iterate_basic_ondemand_f32(const raft_basic_update_weights *wts, const float *fmap1,
+                                    const float *fmap2_pyr, int C, int B, int h, int w, int iters,
+                                    const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1);
+
 /* Profiling twin of raft_iterate_basic_f32 (bench.py only): the same launches with a HIP event
  * recorded on `stream` after every kernel; synchronises the stream and accumulates the elapsed
  * milliseconds of each stage over all iterations into the HOST array stage_ms.  Stage order:

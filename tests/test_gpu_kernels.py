@@ -174,17 +174,23 @@ def test_corr_lookup_axis_quirk(rng):
 
 
 @pytest.mark.parametrize('radius,C', [(4, 256), (3, 128)])
-def test_corr_lookup_ondemand_matches_volume(rng, radius, C):
+# kernel: blocked MFMA (4 x 4 query blocks, default) / wave per query;  flow: smooth-ish (the bounding box of a block
+# fits) / wildly divergent (blocks fall back to one query at a time);  shapes: whole blocks / ragged edges
+@pytest.mark.parametrize('block', ['1', '0'])
+@pytest.mark.parametrize('shape,sigma', [((2, 16, 24), 4.0), ((1, 18, 21), 1.0), ((1, 16, 24), 40.0)])
+def test_corr_lookup_ondemand_matches_volume(rng, radius, C, shape, sigma, block, monkeypatch):
     from tf_raft_amd.layers.corr import CorrBlock
-    B, h, w = 2, 16, 24
+    monkeypatch.setenv('RAFT_ONDEMAND_BLOCK', block)
+    B, h, w = shape
     f1 = rng.normal(size=(B, h, w, C)).astype(np.float32)
     f2 = rng.normal(size=(B, h, w, C)).astype(np.float32)
     vol = CorrBlock(f1, f2, 4, radius)
     alt = CorrBlock(f1, f2, 4, radius, alternate=True)
     import oracle
-    coords = oracle.coords_grid(B, h, w).numpy() + rng.normal(scale=4.0, size=(B, h, w, 2)).astype(np.float32)
+    coords = oracle.coords_grid(B, h, w).numpy() + rng.normal(scale=sigma, size=(B, h, w, 2)).astype(np.float32)
     a, b = _np(vol.retrieve(coords)), _np(alt.retrieve(coords))
-    report(f'ondemand r={radius} C={C}', max_abs=float(np.abs(a - b).max()), scale=float(np.abs(a).max()))
+    report(f'ondemand r={radius} C={C} {shape} sigma={sigma} block={block}', max_abs=float(np.abs(a - b).max()),
+           scale=float(np.abs(a).max()), nonzero=float((a != 0).mean()))
     np.testing.assert_allclose(b, a, atol=2e-5 * max(1.0, float(np.abs(a).max())), rtol=0)
     with pytest.raises(AttributeError):
         alt.corr_pyramid

@@ -79,6 +79,8 @@ _SIGNATURES = {
                                     C.POINTER(State), _P, _P]),
     'raft_iterate_basic_overlap_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
                                             C.POINTER(State), _P, _P, _P, _P]),
+    'raft_iterate_basic_ondemand_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, _P, _I, _I, _I, _I, _I,
+                                        C.POINTER(State), _P, _P, _P, _P]),
     'raft_iterate_basic_timed_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
                                           C.POINTER(State), _P, _P, C.POINTER(C.c_float)]),
     'raft_encoder_workspace_floats': (C.c_int64, [C.POINTER(EncoderWeights), _I, _I, _I]),

@@ -657,15 +657,48 @@ extern "C" int raft_iterate_basic_f32(const raft_basic_update_weights *wts, cons
     return RAFT_OK;
 }
 
+// Where the loop's correlation features come from: the stored pyramid, or fmap1 + the pooled fmap2 pyramid (on demand).
+struct LookupSource {
+    const float *pyr;
+    const int64_t *level_offsets;
+    const float *fmap1, *fmap2_pyr;
+    int C;
+};
+static int loop_lookup(const LookupSource &src, const raft_state *st, int B, int h, int w, void *stream) {
+    if (src.pyr) return raft_corr_lookup_f32(src.pyr, src.level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream);
+    return raft_corr_lookup_ondemand_f32(src.fmap1, src.fmap2_pyr, st->coords1, B, h, w, src.C, 4, 4, st->corr, CORR_LD, stream);
+}
+
+static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, const LookupSource &src, int B, int h, int w,
+                                      int iters, const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1);
+
 // raft_iterate_basic_f32 on three streams (see struct Overlap).  aux0 / aux1 are caller-owned streams
 // distinct from `stream`; all work is joined back into `stream` before returning.
 extern "C" int raft_iterate_basic_overlap_f32(const raft_basic_update_weights *wts, const float *pyr,
                                               const int64_t *level_offsets, int B, int h, int w, int iters,
                                               const raft_state *st, float *flow_up, void *stream, void *aux0,
                                               void *aux1) {
-    RAFT_REQUIRE_PTR(wts);
     RAFT_REQUIRE_PTR(pyr);
     RAFT_REQUIRE_PTR(level_offsets);
+    const LookupSource src = {pyr, level_offsets, nullptr, nullptr, 0};
+    return iterate_basic_overlap_impl(wts, src, B, h, w, iters, st, flow_up, stream, aux0, aux1);
+}
+
+// The same three-stream loop with the volume-free ("alternate") correlation: every iteration's lookup computes its
+// footprint correlations from fmap1 and the pooled fmap2 pyramid (raft_fmap_pyramid_f32).  BASELINE config 4.
+extern "C" int raft_iterate_basic_ondemand_f32(const raft_basic_update_weights *wts, const float *fmap1,
+                                               const float *fmap2_pyr, int C, int B, int h, int w, int iters,
+                                               const raft_state *st, float *flow_up, void *stream, void *aux0,
+                                               void *aux1) {
+    RAFT_REQUIRE_PTR(fmap1);
+    RAFT_REQUIRE_PTR(fmap2_pyr);
+    const LookupSource src = {nullptr, nullptr, fmap1, fmap2_pyr, C};
+    return iterate_basic_overlap_impl(wts, src, B, h, w, iters, st, flow_up, stream, aux0, aux1);
+}
+
+static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, const LookupSource &src, int B, int h, int w,
+                                      int iters, const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1) {
+    RAFT_REQUIRE_PTR(wts);
     RAFT_REQUIRE_PTR(flow_up);
     RAFT_REQUIRE_PTR(aux0);
     RAFT_REQUIRE_PTR(aux1);
@@ -684,7 +717,7 @@ extern "C" int raft_iterate_basic_overlap_f32(const raft_basic_update_weights *w
     const int64_t up = (int64_t)B * 64 * h * w * 2;
     if (rc == RAFT_OK) rc = (int)hipEventRecord(ov.e_fh, s);   // state prepared on `stream`: the flow branch may start
     for (int i = 0; i < iters && rc == RAFT_OK; ++i) {
-        rc = raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream);
+        rc = loop_lookup(src, st, B, h, w, stream);
         if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov);
         // upsample on the mask branch: needs mask2 (same stream) and the flow written by fh2
         if (rc == RAFT_OK) rc = (int)hipStreamWaitEvent(ov.s2, ov.e_fh, 0);

@@ -150,6 +150,16 @@ class RAFT:
                                                 _dev.stream_ptr()), 'iterate_basic')
 
     def _iterate_alternate(self, corr: CorrBlock, st, iters, flow_up):
+        if self.variant == 'raft' and self.overlap:
+            # the same three-stream C loop, lookups computed on demand from fmap1 and the pooled fmap2 pyramid
+            dev = flow_up.device
+            if self._aux is None or self._aux[0].device != dev:
+                self._aux = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            check(_dev.lib().raft_iterate_basic_ondemand_f32(
+                C.byref(self.update_block.c), _dev.ptr(corr.fmap1), _dev.ptr(corr._f2pyr), corr.fmap1.shape[-1],
+                st.B, st.h, st.w, iters, C.byref(st.c), _dev.ptr(flow_up), _dev.stream_ptr(),
+                self._aux[0].cuda_stream, self._aux[1].cuda_stream), 'iterate_basic_ondemand')
+            return
         g = st.g
         for i in range(iters):
             corr.retrieve(st.coords1, out=st.corr, ld_out=g['corr_ld'])

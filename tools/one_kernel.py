@@ -96,6 +96,25 @@ def main():
         ms = timed(run, reps)
         bytes_ = B * H * W * (4 * 100 * 4 + 8 + 324 * 4)
         print(f'lookup {ver} B={B}: {ms*1e3:.1f} us  {bytes_ / ms / 1e6:.0f} GB/s algorithmic')
+    elif kind == 'ondemand':
+        # python tools/one_kernel.py ondemand <sigma> [h] [w] [reps]   (B = 1, C = 256, radius 4; RAFT_ONDEMAND_BLOCK=0/1)
+        sigma = float(sys.argv[2])
+        h = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+        w = int(sys.argv[4]) if len(sys.argv) > 4 else 128
+        reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+        from tf_raft_amd.layers.corr import CorrBlock
+        f1 = rng.normal(size=(1, h, w, 256)).astype(np.float32)
+        f2 = rng.normal(size=(1, h, w, 256)).astype(np.float32)
+        corr = CorrBlock(f1, f2, 4, 4, alternate=True)
+        ys, xs = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing='ij')
+        coords = np.stack([xs, ys], -1)[None] + rng.normal(scale=sigma, size=(1, h, w, 2)).astype(np.float32)
+        coords_d = _dev.to_device(coords)
+        out = torch.empty((1, h, w, 352), device=coords_d.device)
+
+        def run():
+            corr.retrieve(coords_d, out=out, ld_out=352)
+        ms = timed(run, reps)
+        print(f'ondemand lookup {h}x{w} sigma={sigma} block={os.environ.get("RAFT_ONDEMAND_BLOCK", "1")}: {ms*1e3:.1f} us')
     elif kind == 'upsample':
         B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
         reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
