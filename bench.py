@@ -185,6 +185,19 @@ def main():
                    'collective': 'all_gather(flow_predictions[-1]) over RCCL' if world > 1 else 'none'},
     }
 
+    if rank == 0 and world == 1:
+        # ---------------- informational: RAFT.predict_step (flow_predictions[-1] only: mask head + upsampling in the
+        # last iteration only, reference model.py:160-166) -- NOT the headline, which produces all 24 predictions
+        for _ in range(2):
+            model.predict_step((img1, img2))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = max(1, min(args.steps, 5))
+        for _ in range(n):
+            model.predict_step((img1, img2))
+        torch.cuda.synchronize()
+        result['predict_step_pairs_per_s'] = round(B * n / (time.perf_counter() - t0), 3)
+
     if rank == 0:
         # ---------------- instrumented replay: per-kernel HIP-event timing on the launch stream
         h, w = H // 8, W // 8

@@ -186,6 +186,8 @@ typedef struct raft_basic_update_weights {
     /* optional: 1-D Winograd F(2, 5) transformed copies of gru_zr{1,2} / gru_q{1,2}: U = G' g packed as a 6-tap
      * kernel (6, Cin/4, npad, 4) -- tf_raft_amd/packing.py pack_conv_winograd1d */
     raft_conv_weights gru_zr1_w, gru_q1_w, gru_zr2_w, gru_q2_w;
+    /* optional: Winograd F(2x2, 3x3) copy of flow_head.conv1 ALONE (3,3,128,256), for raft_iterate_basic_final_f32 */
+    raft_conv_weights fh1_w;
 } raft_basic_update_weights;
 
 /* Device state of the recurrent loop (all caller-owned, (B*h*w) pixels, NHWC):
@@ -241,6 +243,13 @@ int raft_iterate_basic_overlap_f32(const raft_basic_update_weights *wts, const f
 int raft_iterate_basic_ondemand_f32(const raft_basic_update_weights *wts, const float *fmap1,
                                     const float *fmap2_pyr, int C, int B, int h, int w, int iters,
                                     const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1);
+
+/* The three-stream loop for callers that want flow_predictions[-1] only (reference model.py:160-166, predict_step):
+ * mask head + convex upsampling run in the last iteration only; flow_up_last: (B, 8h, 8w, 2).  The recurrence is launch
+ * for launch that of raft_iterate_basic_overlap_f32, so the result equals its last prediction.  Needs wts->fh1_w. */
+int raft_iterate_basic_final_f32(const raft_basic_update_weights *wts, const float *pyr,
+                                 const int64_t *level_offsets, int B, int h, int w, int iters,
+                                 const raft_state *st, float *flow_up_last, void *stream, void *aux0, void *aux1);
 
 /* Profiling twin of raft_iterate_basic_f32 (bench.py only): the same launches with a HIP event
  * recorded on `stream` after every kernel; synchronises the stream and accumulates the elapsed

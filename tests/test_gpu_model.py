@@ -66,6 +66,21 @@ def test_output_is_list_of_iters_flows(cls_name):
     np.testing.assert_allclose(last.numpy(), out[-1].numpy(), atol=1e-3)
 
 
+def test_predict_step_final_only_loop_equals_last_prediction():
+    """reference model.py:160-166.  RAFT.predict_step skips the mask head + upsampling in all but the last iteration
+    (raft_iterate_basic_final_f32); the recurrence is unchanged, so the flow must be bit-identical to call()[-1]."""
+    import tf_raft_amd
+    from tf_raft_amd import weights as wm
+    model = tf_raft_amd.RAFT(weights=wm.init_weights('raft', seed=4, perturb=True), iters_pred=5)
+    i1, i2 = _images(9, 2, 64, 96)
+    full = model([i1, i2])
+    last = model.predict_step((i1, i2))
+    assert tuple(last.shape) == (2, 64, 96, 2)
+    np.testing.assert_array_equal(last.numpy(), full[-1].numpy())
+    small = tf_raft_amd.SmallRAFT(iters_pred=3)                      # SmallRAFT: predict_step is call()[-1]
+    np.testing.assert_array_equal(small.predict_step((i1, i2)).numpy(), small([i1, i2])[-1].numpy())
+
+
 def test_hip_loop_is_deterministic():
     """Same feature maps, same state -> bit-identical predictions from two runs of the HIP loop."""
     import tf_raft_amd

@@ -27,7 +27,7 @@ class BasicUpdateWeights(C.Structure):
         'gru_zr1', 'gru_q1', 'gru_zr2', 'gru_q2',
         'fh1_mask0', 'fh2', 'mask2', 'gru_ctx1', 'gru_ctx2',
         'convc2_w', 'convf2_w', 'conv_w', 'fh1_mask0_w',
-        'gru_zr1_w', 'gru_q1_w', 'gru_zr2_w', 'gru_q2_w')]
+        'gru_zr1_w', 'gru_q1_w', 'gru_zr2_w', 'gru_q2_w', 'fh1_w')]
 
 
 class SmallUpdateWeights(C.Structure):
@@ -81,6 +81,8 @@ _SIGNATURES = {
                                             C.POINTER(State), _P, _P, _P, _P]),
     'raft_iterate_basic_ondemand_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, _P, _I, _I, _I, _I, _I,
                                         C.POINTER(State), _P, _P, _P, _P]),
+    'raft_iterate_basic_final_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
+                                          C.POINTER(State), _P, _P, _P, _P]),
     'raft_iterate_basic_timed_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
                                           C.POINTER(State), _P, _P, C.POINTER(C.c_float)]),
     'raft_encoder_workspace_floats': (C.c_int64, [C.POINTER(EncoderWeights), _I, _I, _I]),

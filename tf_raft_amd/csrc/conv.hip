@@ -539,8 +539,10 @@ struct Overlap {
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
+// with_mask = false (final-only prediction, every iteration but the last): the mask branch -- mask.0 (the second half of
+// fh1_mask0) and mask.2 -- is skipped; flow_head.conv1 alone runs from wts->fh1_w.
 static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h, int w, const raft_state *st,
-                             void *stream, StageTimer *tm, Overlap *ov = nullptr) {
+                             void *stream, StageTimer *tm, Overlap *ov = nullptr, bool with_mask = true) {
     RAFT_REQUIRE_PTR(wts);
     RAFT_TRY(check_state(st));
     RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
@@ -609,10 +611,13 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         }
     }
     if (ov && ov->have_up) RAFT_HIP(hipStreamWaitEvent(s, ov->e_up, 0));   // mask2 / upsample of the previous iteration
-    {   // relu(flow_head.conv1(net)) | relu(mask.0(net))   3x3, 128 -> 256 + 256
+    if (with_mask) {   // relu(flow_head.conv1(net)) | relu(mask.0(net))   3x3, 128 -> 256 + 256
         ConvArgs a = conv_args(wts->fh1_mask0, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 512, fm, 512);
         RAFT_TRY(launch_conv3x3(wts->fh1_mask0, wts->fh1_mask0_w, 8, a, EPI_RELU, s));
         RAFT_MARK();
+    } else {           // relu(flow_head.conv1(net)) only            3x3, 128 -> 256        -> fm[:, 0:256]
+        ConvArgs a = conv_args(wts->fh1_w, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 256, fm, 512);
+        RAFT_TRY(raft_launch_conv_wino(a, EPI_RELU, s));
     }
     if (ov) {
         RAFT_HIP(hipEventRecord(ov->e_fm, s));
@@ -625,7 +630,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         RAFT_MARK();
     }
     if (ov) RAFT_HIP(hipEventRecord(ov->e_fh, s));
-    {   // mask = 0.25 * mask.2(.)             1x1, 256 -> 576
+    if (with_mask) {   // mask = 0.25 * mask.2(.)             1x1, 256 -> 576
         ConvArgs a = conv_args(wts->mask2, fm + 256, 512, 256, nullptr, 0, 0, B, h, w, 576, st->mask, 576);
         a.scale = 0.25f;
         RAFT_TRY(raft_launch_conv(a, 1, 1, EPI_LINEAR, sm));
@@ -670,7 +675,8 @@ static int loop_lookup(const LookupSource &src, const raft_state *st, int B, int
 }
 
 static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, const LookupSource &src, int B, int h, int w,
-                                      int iters, const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1);
+                                      int iters, const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1,
+                                      bool final_only = false);
 
 // raft_iterate_basic_f32 on three streams (see struct Overlap).  aux0 / aux1 are caller-owned streams
 // distinct from `stream`; all work is joined back into `stream` before returning.
@@ -696,8 +702,25 @@ extern "C" int raft_iterate_basic_ondemand_f32(const raft_basic_update_weights *
     return iterate_basic_overlap_impl(wts, src, B, h, w, iters, st, flow_up, stream, aux0, aux1);
 }
 
+// The prediction loop for callers that only want flow_predictions[-1] (reference model.py:160-166, predict_step): the
+// mask head and the convex upsampling run in the LAST iteration only; flow_up_last: (B, 8h, 8w, 2).  The recurrence
+// (lookup, motion encoder, GRU, flow head) is launch for launch the one of raft_iterate_basic_overlap_f32, so the
+// result equals its last prediction.  Needs the Winograd copy of flow_head.conv1 (wts->fh1_w).
+extern "C" int raft_iterate_basic_final_f32(const raft_basic_update_weights *wts, const float *pyr,
+                                            const int64_t *level_offsets, int B, int h, int w, int iters,
+                                            const raft_state *st, float *flow_up_last, void *stream, void *aux0,
+                                            void *aux1) {
+    RAFT_REQUIRE_PTR(wts);
+    RAFT_REQUIRE_PTR(pyr);
+    RAFT_REQUIRE_PTR(level_offsets);
+    RAFT_REQUIRE(wts->fh1_w.wp != nullptr, RAFT_E_NULL);
+    const LookupSource src = {pyr, level_offsets, nullptr, nullptr, 0};
+    return iterate_basic_overlap_impl(wts, src, B, h, w, iters, st, flow_up_last, stream, aux0, aux1, true);
+}
+
 static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, const LookupSource &src, int B, int h, int w,
-                                      int iters, const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1) {
+                                      int iters, const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1,
+                                      bool final_only) {
     RAFT_REQUIRE_PTR(wts);
     RAFT_REQUIRE_PTR(flow_up);
     RAFT_REQUIRE_PTR(aux0);
@@ -717,11 +740,13 @@ static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, cons
     const int64_t up = (int64_t)B * 64 * h * w * 2;
     if (rc == RAFT_OK) rc = (int)hipEventRecord(ov.e_fh, s);   // state prepared on `stream`: the flow branch may start
     for (int i = 0; i < iters && rc == RAFT_OK; ++i) {
+        const bool with_mask = !final_only || i == iters - 1;
         rc = loop_lookup(src, st, B, h, w, stream);
-        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov);
+        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov, with_mask);
+        if (!with_mask) continue;
         // upsample on the mask branch: needs mask2 (same stream) and the flow written by fh2
         if (rc == RAFT_OK) rc = (int)hipStreamWaitEvent(ov.s2, ov.e_fh, 0);
-        if (rc == RAFT_OK) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, ov.s2);
+        if (rc == RAFT_OK) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + (final_only ? 0 : i * up), ov.s2);
         if (rc == RAFT_OK) rc = (int)hipEventRecord(ov.e_up, ov.s2);
         ov.have_up = true;
     }

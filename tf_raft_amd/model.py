@@ -134,6 +134,11 @@ class RAFT:
                                                 _dev.stream_ptr()), 'prepare_state')
         self.update_block.prepare(st)          # GRU terms of `inp`: constant over the loop (model.py:86)
 
+    def _aux_streams(self, dev):
+        if self._aux is None or self._aux[0].device != dev:
+            self._aux = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        return self._aux
+
     def _iterate(self, corr: CorrBlock, st, iters, flow_up):
         if self.overlap:
             # flow branch and mask branch of every iteration on two side streams (events inside the library)
@@ -175,6 +180,9 @@ class RAFT:
 
     def call(self, inputs, training=False):
         """reference model.py:68-109."""
+        return self._forward(inputs, training)
+
+    def _forward(self, inputs, training=False, final_only=False):
         image1, image2 = inputs
         image1 = _dev.to_device(image1)
         image2 = _dev.to_device(image2)
@@ -206,6 +214,14 @@ class RAFT:
         st = self._get_state(B, h, w, image1.device)
         self._prepare(cnet, st)                                                 # model.py:84-89
         iters = self.iters if training else self.iters_pred
+        if final_only:
+            last = torch.empty((B, H, W, 2), device=image1.device, dtype=torch.float32)
+            check(_dev.lib().raft_iterate_basic_final_f32(
+                C.byref(self.update_block.c), _dev.ptr(correlation._pyr), correlation._off, B, h, w, iters, C.byref(st.c),
+                _dev.ptr(last), _dev.stream_ptr(), self._aux_streams(last.device)[0].cuda_stream,
+                self._aux_streams(last.device)[1].cuda_stream), 'iterate_basic_final')
+            self._last_correlation = correlation
+            return _dev.wrap(last)
         flow_up = torch.empty((iters, B, H, W, 2), device=image1.device, dtype=torch.float32)
         if self.alternate_corr:
             self._iterate_alternate(correlation, st, iters, flow_up)
@@ -215,8 +231,12 @@ class RAFT:
         return [_dev.wrap(flow_up[i]) for i in range(iters)]                    # model.py:109
 
     def predict_step(self, data):
-        """reference model.py:160-166."""
+        """reference model.py:160-166: ``flow_predictions[-1]`` of the forward pass.  RAFT computes it with the mask head
+        and the convex upsampling in the last iteration only (``raft_iterate_basic_final_f32``: the recurrence itself
+        is unchanged, so the result equals ``self(...)[-1]``)."""
         image1, image2, *_ = data
+        if self.variant == 'raft' and self.overlap and not self.alternate_corr:
+            return self._forward([image1, image2], training=False, final_only=True)
         return self([image1, image2], training=False)[-1]
 
 

@@ -156,7 +156,11 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
         out.append((field, wp, bb, npad))
     # F(2, 5)-transformed copies of the per-iteration SepConvGRU convolutions (field order of the C struct)
     order = ['gru_zr1_w', 'gru_q1_w', 'gru_zr2_w', 'gru_q2_w']
-    return out + sorted(gru_w, key=lambda e: order.index(e[0]))
+    out = out + sorted(gru_w, key=lambda e: order.index(e[0]))
+    # flow_head.conv1 alone (final-only prediction loop: the mask half of fh1_mask0 is skipped)
+    wp, bb, npad = pack_conv_winograd(w[f'{p}/flow_head/conv1/kernel'], w[f'{p}/flow_head/conv1/bias'])
+    out.append(('fh1_w', wp, bb, npad))
+    return out
 
 
 def pack_small_update(weights: Dict[str, np.ndarray], prefix: str = 'update_block'):
