@@ -356,6 +356,42 @@ def test_conv1d_winograd_matches_oracle(rng, shape, ksize, tnw, monkeypatch):
     assert err < 2e-5
 
 
+def test_winograd_kernels_on_random_small_shapes(rng):
+    """Shapes that do not fill a single tile, single rows / columns, odd sizes: both Winograd kernels and the direct
+    halo kernel against the float64 oracle convolution."""
+    from oracle import tf_ops
+    from tf_raft_amd import _dev, packing
+    from tf_raft_amd._ffi import check
+    lib = _dev.lib()
+    shapes = [(1, 1, 1), (1, 1, 7), (1, 2, 33), (1, 3, 2), (2, 4, 32), (1, 5, 31), (3, 7, 3), (1, 9, 65), (1, 17, 16),
+              (2, 1, 40), (1, 12, 34), (1, 33, 5)]
+    for (B, H, W) in shapes:
+        cin, cout = int(rng.choice([16, 32, 48])), int(rng.choice([7, 64, 96]))
+        x = rng.normal(size=(B, H, W, cin)).astype(np.float32)
+        xd = _dev.to_device(x)
+        for kh, kw in ((3, 3), (1, 5), (5, 1)):
+            kernel = (rng.normal(size=(kh, kw, cin, cout)) * 0.1).astype(np.float32)
+            bias = rng.normal(size=(cout,)).astype(np.float32)
+            want = tf_ops.conv2d(_t(x).double(), _t(kernel).double(), _t(bias).double()).numpy()
+            direct = _conv_device([(x, 32 * ((cin + 31) // 32))], kernel, bias, act=0)
+            np.testing.assert_allclose(direct, want, atol=3e-5, rtol=0, err_msg='direct ' + str((B, H, W, kh, kw, cin, cout)))
+            out = torch.full((B, H, W, cout), float('nan'), device=xd.device)
+            pack = packing.pack_conv_winograd if kh == 3 else packing.pack_conv_winograd1d
+            wp, b, npad = pack(kernel, bias, [(cin, 32 * ((cin + 31) // 32))])
+            wp_d, b_d = _dev.to_device(np.ascontiguousarray(wp[:, :cin // 4])), _dev.to_device(b)   # keep alive over the launch
+            if kh == 3:
+                check(lib.raft_conv2d_winograd_f32(_dev.ptr(xd), cin, cin, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W,
+                                                   npad, cout, 0, 1.0, _dev.ptr(out), cout, _dev.stream_ptr()), 'conv2d_winograd')
+            else:
+                check(lib.raft_conv1d_winograd_f32(_dev.ptr(xd), cin, cin, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W,
+                                                   kh, kw, npad, cout, 0, 1.0, _dev.ptr(out), cout, _dev.stream_ptr()),
+                      'conv1d_winograd')
+            torch.cuda.synchronize()
+            got = _np(out)
+            assert not np.isnan(got).any(), (B, H, W, kh, kw, cin, cout)
+            np.testing.assert_allclose(got, want, atol=3e-5, rtol=0, err_msg=str((B, H, W, kh, kw, cin, cout)))
+
+
 def test_basic_update_block_winograd_gru_matches_direct(rng, monkeypatch):
     """RAFT_GRU_WINO=15: the four per-iteration SepConvGRU convolutions on the F(2, 5) kernel (gate epilogues + context)."""
     from tf_raft_amd import weights as wm
