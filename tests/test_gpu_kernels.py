@@ -318,7 +318,7 @@ def test_conv2d_winograd_matches_oracle(rng, shape, variant, monkeypatch):
     assert err < 2e-5
 
 
-@pytest.mark.parametrize('tnw', ['1', '2', '1-ck2', '2-ck2'])
+@pytest.mark.parametrize('tnw', ['1', '2', '1-ck2', '2-ck2', '2-ck2-tm1', '1-tm1', '2-tm2'])   # TNW, CK, TM variants
 @pytest.mark.parametrize('ksize', [(1, 5), (5, 1)])
 @pytest.mark.parametrize('shape', [(2, 9, 13), (1, 8, 64), (1, 21, 35)])
 def test_conv1d_winograd_matches_oracle(rng, shape, ksize, tnw, monkeypatch):
@@ -328,6 +328,8 @@ def test_conv1d_winograd_matches_oracle(rng, shape, ksize, tnw, monkeypatch):
     from tf_raft_amd._ffi import check
     monkeypatch.setenv('RAFT_WINO_TNW', tnw[0])
     monkeypatch.setenv('RAFT_WINO_CK', '2' if 'ck2' in tnw else '1')
+    if 'tm' in tnw:
+        monkeypatch.setenv('RAFT_WINO1D_TM', tnw[-1])
     kh, kw = ksize
     B, H, W = shape
     c_a, c_b, cout = (64 if 'ck2' in tnw else 48), 64, 150          # 32 channels per barrier: sources in multiples of 32

@@ -17,9 +17,9 @@
 //
 //   * an MFMA row is one output PAIR; a row block is 16 pairs.  AXIS 0 (1x5): a row block = 32 consecutive pixels of
 //     one image row (pairs along x), a workgroup owns 4 rows x 32 columns; AXIS 1 (5x1): a row block = 16 consecutive
-//     columns of one row pair (pairs along y), a workgroup owns 8 rows x 16 columns.  Either way 4 row blocks x
-//     BN = 32*TNW channels; wave w -> row blocks {2 (w & 1), 2 (w & 1) + 1}, channel group w >> 1 with TNW column blocks:
-//     2 x 6 x TNW accumulators of 4 registers.  A weight fragment feeds both row blocks, a transformed input both
+//     columns of one row pair (pairs along y), a workgroup owns 8 rows x 16 columns.  Either way 2 TM row blocks x
+//     BN = 32*TNW channels (TM = 2 above); wave w -> row blocks TM (w & 1) + {0 .. TM-1}, channel group w >> 1 with TNW
+//     column blocks: TM x 6 x TNW accumulators of 4 registers.  A weight fragment feeds both row blocks, a transformed input both
 //     column blocks.
 //   * K in 16-channel chunks: halo tile staged once in LDS (AXIS 0: 4 x 36 pixels at 20 floats, AXIS 1: 12 x 16 pixels
 //     at 24 floats: conflict-free ds_read_b128 for lanes stepping 2 / 1 pixels, tools/bank_check.py); a lane reads the
@@ -32,12 +32,12 @@
 
 #include "conv_mfma.h"
 
-// CK = 16-channel chunks staged per barrier (1 or 2).
-template <int AXIS, int TNW, int EPI, int CK = 1>
+// CK = 16-channel chunks staged per barrier (1 or 2).  TM = row blocks per wave (2, or 1: half-height workgroup tiles
+// -- twice the workgroups for layers such as gru_q (N = 128) that otherwise leave under one workgroup per CU).
+template <int AXIS, int TNW, int EPI, int CK = 1, int TM = 2>
 __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
-    constexpr int TM = 2;                                       // row blocks per wave
-    constexpr int TILE_H = AXIS == 0 ? 4 : 8, TILE_W = AXIS == 0 ? 32 : 16;
-    constexpr int HH = AXIS == 0 ? 4 : 12, HWP = AXIS == 0 ? 36 : 16, HP = HH * HWP;   // halo tile
+    constexpr int TILE_H = AXIS == 0 ? 2 * TM : 4 * TM, TILE_W = AXIS == 0 ? 32 : 16;
+    constexpr int HH = AXIS == 0 ? 2 * TM : 4 * TM + 4, HWP = AXIS == 0 ? 36 : 16, HP = HH * HWP;   // halo tile
     constexpr int LDA = AXIS == 0 ? (CK == 1 ? 20 : 36) : (CK == 1 ? 24 : 40);   // floats per halo pixel in LDS
     constexpr int QS = 4 * CK;                                  // 16-byte channel quads per halo pixel per stage
     constexpr int NA = (HP * QS + 255) / 256;
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
     //   AXIS 0: pair LR of image row y0 + rb: inputs at halo (rb, 2 LR + k)      AXIS 1: pair = rows (2 rb, 2 rb + 1) of
     //   column x0 + LR: inputs at halo (2 rb + k, LR),  k = 0..5
     auto a_lane = [&](int i) {
-        const int rb = 2 * rbp + i;
+        const int rb = TM * rbp + i;
         return (AXIS == 0 ? (rb * HWP + 2 * LR) : (2 * rb * HWP + LR)) * LDA + G * 4;
     };
     const unsigned b_lane = (unsigned)(((G * p.npad) + n0 + cg * 16 * TNW + LR) * 16);   // bytes
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
     };
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int rb = 2 * rbp + i;
+        const int rb = TM * rbp + i;
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
             const int n = n0 + (cg * TNW + j) * 16 + LR;

@@ -3,16 +3,22 @@
 
 constexpr bool RAFT_WINO1D_CK2_DEFAULT = true;   // 32 channels per barrier: +2-4 % on the GRU layers (profiles/r03u)
 
-template <int AXIS, int TNW, int CK>
+template <int AXIS, int TNW, int CK, int TM>
 static int launch_wino1d(const ConvArgs &a, int epi, int grid, hipStream_t s) {
     switch (epi) {
-        case EPI_LINEAR: conv_wino1d_kernel<AXIS, TNW, EPI_LINEAR, CK><<<grid, 256, 0, s>>>(a); break;
-        case EPI_RELU: conv_wino1d_kernel<AXIS, TNW, EPI_RELU, CK><<<grid, 256, 0, s>>>(a); break;
-        case EPI_GRU_ZR: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_ZR, CK><<<grid, 256, 0, s>>>(a); break;
-        case EPI_GRU_Q: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_Q, CK><<<grid, 256, 0, s>>>(a); break;
+        case EPI_LINEAR: conv_wino1d_kernel<AXIS, TNW, EPI_LINEAR, CK, TM><<<grid, 256, 0, s>>>(a); break;
+        case EPI_RELU: conv_wino1d_kernel<AXIS, TNW, EPI_RELU, CK, TM><<<grid, 256, 0, s>>>(a); break;
+        case EPI_GRU_ZR: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_ZR, CK, TM><<<grid, 256, 0, s>>>(a); break;
+        case EPI_GRU_Q: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_Q, CK, TM><<<grid, 256, 0, s>>>(a); break;
         default: return RAFT_E_UNSUPPORTED;
     }
     return raft_launch_status();
+}
+
+template <int AXIS, int TM>
+static int launch_wino1d_tm(const ConvArgs &a, int epi, int grid, int tnw, bool ck2, hipStream_t s) {
+    if (ck2) return tnw == 2 ? launch_wino1d<AXIS, 2, 2, TM>(a, epi, grid, s) : launch_wino1d<AXIS, 1, 2, TM>(a, epi, grid, s);
+    return tnw == 2 ? launch_wino1d<AXIS, 2, 1, TM>(a, epi, grid, s) : launch_wino1d<AXIS, 1, 1, TM>(a, epi, grid, s);
 }
 
 int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s) {
@@ -30,21 +36,23 @@ int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStrea
         if ((int64_t)6 * (a.c0 + a.c1) * a.npad * 4 >= lim) return RAFT_E_UNSUPPORTED;
     }
     const int axis = kh == 5 ? 1 : 0;
-    const int tiles = axis == 0 ? a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
-    const char *e = getenv("RAFT_WINO_TNW");   // tuning / test override, read per call
+    const char *e = getenv("RAFT_WINO_TNW");   // tuning / test overrides, read per call
     const int forced = e ? atoi(e) : 0;
-    // 64-channel workgroups (a transformed input feeds two column blocks) beat 32-channel ones even when they leave
-    // under one workgroup per CU (gru_q at B = 4: 224 workgroups, 33.9 vs 36.0 us)
-    int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) >= 200) ? 2 : 1;
-    if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
-    const int grid = tiles * (a.npad / (32 * tnw));
-    // 32 channels per barrier when the channel counts allow it (RAFT_WINO_CK = 1 / 2 overrides)
+    const char *tme = getenv("RAFT_WINO1D_TM");
     const char *cke = getenv("RAFT_WINO_CK");
     const bool ck2 = a.c0 % 32 == 0 && a.c1 % 32 == 0 && (cke ? atoi(cke) == 2 : RAFT_WINO1D_CK2_DEFAULT);
-    if (axis == 0) {
-        if (ck2) return tnw == 2 ? launch_wino1d<0, 2, 2>(a, epi, grid, s) : launch_wino1d<0, 1, 2>(a, epi, grid, s);
-        return tnw == 2 ? launch_wino1d<0, 2, 1>(a, epi, grid, s) : launch_wino1d<0, 1, 1>(a, epi, grid, s);
-    }
-    if (ck2) return tnw == 2 ? launch_wino1d<1, 2, 2>(a, epi, grid, s) : launch_wino1d<1, 1, 2>(a, epi, grid, s);
-    return tnw == 2 ? launch_wino1d<1, 2, 1>(a, epi, grid, s) : launch_wino1d<1, 1, 1>(a, epi, grid, s);
+    auto tiles_of = [&](int tm) {
+        return axis == 0 ? a.B * ((a.H + 2 * tm - 1) / (2 * tm)) * ((a.W + 31) / 32)
+                         : a.B * ((a.H + 4 * tm - 1) / (4 * tm)) * ((a.W + 15) / 16);
+    };
+    // 64-channel workgroups (a transformed input feeds two column blocks) wherever the channel count allows; full-height
+    // tiles (TM = 2) when they still give about two workgroups per CU, half-height tiles otherwise (gru_q at B = 4:
+    // 224 -> 448 workgroups)
+    int tnw = a.npad % 64 == 0 ? 2 : 1;
+    if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
+    int tm = (int64_t)tiles_of(2) * (a.npad / (32 * tnw)) >= 400 ? 2 : 1;
+    if (tme && (atoi(tme) == 1 || atoi(tme) == 2)) tm = atoi(tme);
+    const int grid = tiles_of(tm) * (a.npad / (32 * tnw));
+    if (axis == 0) return tm == 2 ? launch_wino1d_tm<0, 2>(a, epi, grid, tnw, ck2, s) : launch_wino1d_tm<0, 1>(a, epi, grid, tnw, ck2, s);
+    return tm == 2 ? launch_wino1d_tm<1, 2>(a, epi, grid, tnw, ck2, s) : launch_wino1d_tm<1, 1>(a, epi, grid, tnw, ck2, s);
 }
