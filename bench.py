@@ -41,24 +41,27 @@ STAGES = ['corr_lookup', 'convc1', 'convc2', 'convf1', 'convf2', 'conv', 'gru_zr
 
 
 # Layers that run on a Winograd kernel execute fewer multiplies than the convolution they compute: F(2x2, 3x3) 16 per
-# 36 (conv_wino.h), F(2, 5) 6 per 10 (conv_wino1d.h).  `achieved` below always counts the ALGORITHMIC (direct
-# convolution) FLOPs, so it can exceed the fp32 MFMA peak; `executed_tflops` divides by this factor.
-WINOGRAD_MAC_RATIO = {'convc2': 2.25, 'conv': 2.25, 'fh1_mask0': 2.25,
-                      'gru_zr1': 10.0 / 6.0, 'gru_q1': 10.0 / 6.0, 'gru_zr2': 10.0 / 6.0, 'gru_q2': 10.0 / 6.0}
+# 36 (conv_wino.h), F(2, 5) 6 per 10 and F(4, 5) 8 per 20 (conv_wino1d.h).  `achieved` below always counts the
+# ALGORITHMIC (direct convolution) FLOPs, so it can exceed the fp32 MFMA peak; `executed_tflops` divides by this factor.
+WINOGRAD_ALGORITHMS = {2.25: 'Winograd F(2x2,3x3)', 10.0 / 6.0: 'Winograd F(2,5)', 2.5: 'Winograd F(4,5)'}
 
 
 def winograd_layers():
-    """Stage names that are on a Winograd kernel under the current RAFT_CONV_WINO / RAFT_GRU_WINO switches
-    (defaults of csrc/conv.hip: 3x3 mask 13 = convc2 | conv | fh1_mask0, GRU mask 15)."""
+    """{stage name: direct MACs / executed MACs} of the stages that are on a Winograd kernel under the current
+    RAFT_CONV_WINO / RAFT_GRU_WINO / RAFT_GRU_WINO4 switches (defaults of csrc/conv.hip: 3x3 mask 13 = convc2 | conv |
+    fh1_mask0, GRU masks 15: F(4, 5) where its bit is set, else F(2, 5))."""
     m3 = int(os.environ.get('RAFT_CONV_WINO', '13'))
     mg = int(os.environ.get('RAFT_GRU_WINO', '15'))
-    on = set()
+    mg4 = int(os.environ.get('RAFT_GRU_WINO4', '15'))
+    on = {}
     for bit, name in ((1, 'convc2'), (2, 'convf2'), (4, 'conv'), (8, 'fh1_mask0')):
         if m3 & bit:
-            on.add(name)
+            on[name] = 2.25
     for bit, name in ((1, 'gru_zr1'), (2, 'gru_q1'), (4, 'gru_zr2'), (8, 'gru_q2')):
-        if mg & bit:
-            on.add(name)
+        if mg4 & bit:
+            on[name] = 2.5
+        elif mg & bit:
+            on[name] = 10.0 / 6.0
     return on
 
 
@@ -247,8 +250,8 @@ def main():
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': tr,
                     'flops_per_launch': flops[dom], 'ms_per_launch': stage_ms[dom], 'traffic_source': note}
             if dom in winograd_layers():
-                ratio = WINOGRAD_MAC_RATIO.get(dom, 2.25)
-                roof['algorithm'] = ('Winograd F(2x2,3x3)' if ratio == 2.25 else 'Winograd F(2,5)') + \
+                ratio = winograd_layers()[dom]
+                roof['algorithm'] = WINOGRAD_ALGORITHMS[ratio] + \
                     ': achieved counts the direct convolution FLOPs (the algorithmic figure), executed_tflops the MFMA FLOPs issued'
                 roof['executed_tflops'] = round(ach / ratio, 2)
                 roof['frac_executed'] = round(ach / ratio / PEAK_FP32_MFMA_TFLOPS, 4)
@@ -281,9 +284,9 @@ def main():
         result['update_block_tflops'] = round(sum(flops.values()) / (mfma_ms * 1e-3) / 1e12, 2)
         wl = winograd_layers()
         result['update_block_executed_tflops'] = round(
-            sum(v / (WINOGRAD_MAC_RATIO[k] if k in wl and k in WINOGRAD_MAC_RATIO else 1.0) for k, v in flops.items())
+            sum(v / wl.get(k, 1.0) for k, v in flops.items())
             / (mfma_ms * 1e-3) / 1e12, 2)
-        result['winograd_layers'] = sorted(wl)
+        result['winograd_layers'] = {k: WINOGRAD_ALGORITHMS[wl[k]] for k in sorted(wl)}
         result['stage_ms'] = stage_ms
         result['pre_loop_ms'] = {k: round(v, 4) for k, v in pre_ms.items()}
         result['roofline_timing'] = 'HIP events on the launch stream, instrumented replay of the timed steps'

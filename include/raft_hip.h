@@ -157,6 +157,12 @@ int raft_conv1d_winograd_f32(const float *a0, int lda0, int c0, const float *a1,
                              const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
                              int npad, int nvalid, int act, float scale, float *out, int ldo, void *stream);
 
+/* The same by 1-D Winograd F(4, 5) (8 multiplies per 4 outputs; points {0, +-1, +-1/2, +-2, inf}).  `wp` = the
+ * transformed kernel packed with 8 taps (packing.py pack_conv_winograd1d(..., m=4)); c0, c1 multiples of 32. */
+int raft_conv1d_winograd4_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                              const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
+                              int npad, int nvalid, int act, float scale, float *out, int ldo, void *stream);
+
 /* ------------------------------------------------------------------ update block */
 
 typedef struct raft_conv_weights {
@@ -188,6 +194,9 @@ typedef struct raft_basic_update_weights {
     raft_conv_weights gru_zr1_w, gru_q1_w, gru_zr2_w, gru_q2_w;
     /* optional: Winograd F(2x2, 3x3) copy of flow_head.conv1 ALONE (3,3,128,256), for raft_iterate_basic_final_f32 */
     raft_conv_weights fh1_w;
+    /* optional: 1-D Winograd F(4, 5) transformed copies of gru_zr{1,2} / gru_q{1,2}, packed as 8-tap kernels
+     * (8, Cin/4, npad, 4) -- pack_conv_winograd1d(..., m=4); preferred over the F(2, 5) copies when supplied */
+    raft_conv_weights gru_zr1_w4, gru_q1_w4, gru_zr2_w4, gru_q2_w4;
 } raft_basic_update_weights;
 
 /* Device state of the recurrent loop (all caller-owned, (B*h*w) pixels, NHWC):

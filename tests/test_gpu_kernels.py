@@ -358,6 +358,56 @@ def test_conv1d_winograd_matches_oracle(rng, shape, ksize, tnw, monkeypatch):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize('tnw', ['1', '2'])
+@pytest.mark.parametrize('ksize', [(1, 5), (5, 1)])
+@pytest.mark.parametrize('shape', [(2, 9, 13), (1, 8, 64), (1, 21, 35), (1, 3, 131), (1, 67, 5)])
+def test_conv1d_winograd4_matches_oracle(rng, shape, ksize, tnw, monkeypatch):
+    """1-D Winograd F(4, 5) kernel (conv_wino1d.h, MO = 4) against the float64 direct convolution; two sources, N tail,
+    tiles cut by the right / bottom border."""
+    from oracle import tf_ops
+    from tf_raft_amd import _dev, packing
+    from tf_raft_amd._ffi import check
+    monkeypatch.setenv('RAFT_WINO_TNW', tnw)
+    kh, kw = ksize
+    B, H, W = shape
+    c_a, c_b, cout = 32, 64, 150
+    xa = rng.normal(size=(B, H, W, c_a)).astype(np.float32)
+    xb = rng.normal(size=(B, H, W, c_b)).astype(np.float32)
+    kernel = (rng.normal(size=(kh, kw, c_a + c_b, cout)) * 0.1).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    sa, sb = _dev.to_device(xa), _dev.to_device(xb)
+    wp, b, npad = packing.pack_conv_winograd1d(kernel, bias, [(c_a, 32), (c_b, 64)], m=4)
+    assert wp.shape == (8, 24, npad, 4)
+    wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
+    out = torch.full((B, H, W, cout), float('nan'), device=sa.device)
+    check(_dev.lib().raft_conv1d_winograd4_f32(_dev.ptr(sa), c_a, c_a, _dev.ptr(sb), c_b, c_b, _dev.ptr(wp_d), _dev.ptr(b_d),
+                                               B, H, W, kh, kw, npad, cout, 1, 0.5, _dev.ptr(out), cout, _dev.stream_ptr()),
+          'conv1d_winograd4')
+    torch.cuda.synchronize()
+    got = _np(out)
+    x = torch.cat([_t(xa), _t(xb)], dim=-1)
+    want = 0.5 * torch.relu(tf_ops.conv2d(x.double(), _t(kernel).double(), _t(bias).double())).numpy()
+    direct = _conv_device([(xa, 32), (xb, 64)], kernel, bias, act=1, scale=0.5)
+    err, err_direct = float(np.abs(got - want).max()), float(np.abs(direct - want).max())
+    report(f'conv1d winograd F(4,5) {ksize} {shape} tnw {tnw}', max_abs_vs_f64=err, direct_vs_f64=err_direct)
+    assert not np.isnan(got).any()
+    assert err < 2e-5
+
+
+def test_conv1d_winograd4_rejects_16_channel_sources(rng):
+    """F(4, 5) stages 32 channels per barrier: sources that are not multiples of 32 are refused, not mis-computed."""
+    from tf_raft_amd import _dev, packing
+    x = _dev.to_device(rng.normal(size=(1, 4, 8, 48)).astype(np.float32))
+    kernel = rng.normal(size=(1, 5, 48, 32)).astype(np.float32)
+    wp, b, npad = packing.pack_conv_winograd1d(kernel, np.zeros(32, np.float32), [(48, 64)], m=4)
+    wp_d, b_d = _dev.to_device(np.ascontiguousarray(wp[:, :12])), _dev.to_device(b)
+    out = torch.zeros((1, 4, 8, 32), device=x.device)
+    rc = _dev.lib().raft_conv1d_winograd4_f32(_dev.ptr(x), 48, 48, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), 1, 4, 8, 1, 5,
+                                              npad, 32, 0, 1.0, _dev.ptr(out), 32, _dev.stream_ptr())
+    torch.cuda.synchronize()
+    assert rc != 0
+
+
 def test_winograd_kernels_on_random_small_shapes(rng):
     """Shapes that do not fill a single tile, single rows / columns, odd sizes: both Winograd kernels and the direct
     halo kernel against the float64 oracle convolution."""
@@ -392,10 +442,22 @@ def test_winograd_kernels_on_random_small_shapes(rng):
             got = _np(out)
             assert not np.isnan(got).any(), (B, H, W, kh, kw, cin, cout)
             np.testing.assert_allclose(got, want, atol=3e-5, rtol=0, err_msg=str((B, H, W, kh, kw, cin, cout)))
+            if kh != 3 and cin % 32 == 0:   # F(4, 5)
+                out4 = torch.full((B, H, W, cout), float('nan'), device=xd.device)
+                wp4, b4, npad4 = packing.pack_conv_winograd1d(kernel, bias, [(cin, cin)], m=4)
+                wp4_d, b4_d = _dev.to_device(wp4), _dev.to_device(b4)
+                check(lib.raft_conv1d_winograd4_f32(_dev.ptr(xd), cin, cin, None, 0, 0, _dev.ptr(wp4_d), _dev.ptr(b4_d), B, H, W,
+                                                    kh, kw, npad4, cout, 0, 1.0, _dev.ptr(out4), cout, _dev.stream_ptr()),
+                      'conv1d_winograd4')
+                torch.cuda.synchronize()
+                got4 = _np(out4)
+                assert not np.isnan(got4).any(), (B, H, W, kh, kw, cin, cout)
+                np.testing.assert_allclose(got4, want, atol=3e-5, rtol=0, err_msg='F(4,5) ' + str((B, H, W, kh, kw, cin, cout)))
 
 
 def test_basic_update_block_winograd_gru_matches_direct(rng, monkeypatch):
-    """RAFT_GRU_WINO=15: the four per-iteration SepConvGRU convolutions on the F(2, 5) kernel (gate epilogues + context)."""
+    """RAFT_GRU_WINO=15 / RAFT_GRU_WINO4=15: the four per-iteration SepConvGRU convolutions on the F(2, 5) and F(4, 5)
+    kernels (gate epilogues + context) against the direct kernels."""
     from tf_raft_amd import weights as wm
     from tf_raft_amd.layers.update import BasicUpdateBlock
     wts = wm.init_weights('raft', seed=3, perturb=True)
@@ -403,6 +465,7 @@ def test_basic_update_block_winograd_gru_matches_direct(rng, monkeypatch):
         net, inp, corr, flow = _update_inputs(rng, 'raft', *shape)
         blk = BasicUpdateBlock(filters=128, weights=wts)
         monkeypatch.setenv('RAFT_GRU_WINO', '0')
+        monkeypatch.setenv('RAFT_GRU_WINO4', '0')
         dn, dm, dd = [_np(t) for t in blk([net, inp, corr, flow])]
         monkeypatch.setenv('RAFT_GRU_WINO', '15')
         wn, wmk, wd = [_np(t) for t in blk([net, inp, corr, flow])]
@@ -410,6 +473,12 @@ def test_basic_update_block_winograd_gru_matches_direct(rng, monkeypatch):
                mask=float(np.abs(wmk - dm).max()), delta=float(np.abs(wd - dd).max()))
         assert np.abs(wn - dn).max() < 2e-5 and np.abs(wmk - dm).max() < 5e-5 and np.abs(wd - dd).max() < 5e-5
         assert np.abs(wn - dn).max() > 0
+        monkeypatch.setenv('RAFT_GRU_WINO4', '15')
+        vn, vmk, vd = [_np(t) for t in blk([net, inp, corr, flow])]
+        report(f'update block F(4,5) GRU vs direct {shape}', net=float(np.abs(vn - dn).max()),
+               mask=float(np.abs(vmk - dm).max()), delta=float(np.abs(vd - dd).max()))
+        assert np.abs(vn - dn).max() < 2e-5 and np.abs(vmk - dm).max() < 5e-5 and np.abs(vd - dd).max() < 5e-5
+        assert np.abs(vn - dn).max() > 0 and np.abs(vn - wn).max() > 0
 
 
 def test_small_update_block_winograd_layers_match_direct(rng, monkeypatch):

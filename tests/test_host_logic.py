@@ -227,6 +227,35 @@ def test_pack_encoder_folds_batch_norm_and_covers_every_layer(rng):
     assert len(enc.block_w) == 6 and len(enc.block_w[0]) == 2
 
 
+@pytest.mark.parametrize('m', [2, 4])
+@pytest.mark.parametrize('ksize', [(1, 5), (5, 1)])
+def test_winograd1d_transforms_reproduce_the_convolution(rng, m, ksize):
+    """A^T [(G' g) . (B'^T d)] == the 5-tap correlation, for the F(2, 5) and F(4, 5) matrices the HIP kernel hard-codes
+    (csrc/conv_wino1d.h) and the packed layout it reads."""
+    kh, kw = ksize
+    cin, cout = 32, 24
+    kernel = rng.normal(size=(kh, kw, cin, cout))
+    U = packing.winograd1d_kernel(kernel, m)
+    assert U.shape == (m + 4, 1, cin, cout) and U.dtype == np.float32
+    BT, AT = (packing.WINO1D_BT, packing.WINO1D_AT) if m == 2 else (packing.WINO1D4_BT, packing.WINO1D4_AT)
+    assert BT.shape == (m + 4, m + 4) and AT.shape == (m, m + 4)
+    assert np.all(BT == np.round(BT))                       # integer input transform: exact products in fp32
+    d = rng.normal(size=(m + 4, cin))
+    V = BT @ d                                              # (taps, cin)
+    y = AT @ np.einsum('tc,tco->to', V, U[:, 0].astype(np.float64))
+    g = kernel.reshape(5, cin, cout)
+    want = np.stack([np.einsum('kc,kco->o', d[i:i + 5], g) for i in range(m)])
+    np.testing.assert_allclose(y, want, atol=2e-5, rtol=0)  # U is rounded to fp32 once
+    wp, b, npad = packing.pack_conv_winograd1d(kernel.astype(np.float32), np.zeros(cout, np.float32), [(cin, cin)], m=m)
+    assert wp.shape == (m + 4, cin // 4, npad, 4) and npad % 32 == 0 and npad >= cout
+    np.testing.assert_array_equal(wp[3].transpose(0, 2, 1).reshape(cin, npad)[:, :cout],
+                                  packing.winograd1d_kernel(kernel.astype(np.float32), m)[3, 0])
+    with pytest.raises(ValueError):
+        packing.winograd1d_kernel(kernel, 3)
+    with pytest.raises(ValueError):
+        packing.winograd1d_kernel(rng.normal(size=(3, 3, 4, 4)), m)
+
+
 # ---------------------------------------------------------------- C ABI
 def _declared_functions():
     with open(os.path.join(ROOT, 'include', 'raft_hip.h')) as f:

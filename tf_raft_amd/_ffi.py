@@ -27,7 +27,8 @@ class BasicUpdateWeights(C.Structure):
         'gru_zr1', 'gru_q1', 'gru_zr2', 'gru_q2',
         'fh1_mask0', 'fh2', 'mask2', 'gru_ctx1', 'gru_ctx2',
         'convc2_w', 'convf2_w', 'conv_w', 'fh1_mask0_w',
-        'gru_zr1_w', 'gru_q1_w', 'gru_zr2_w', 'gru_q2_w', 'fh1_w')]
+        'gru_zr1_w', 'gru_q1_w', 'gru_zr2_w', 'gru_q2_w', 'fh1_w',
+        'gru_zr1_w4', 'gru_q1_w4', 'gru_zr2_w4', 'gru_q2_w4')]
 
 
 class SmallUpdateWeights(C.Structure):
@@ -71,6 +72,7 @@ _SIGNATURES = {
                              C.c_float, _P, _I, _P]),
     'raft_conv2d_winograd_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),
     'raft_conv1d_winograd_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),
+    'raft_conv1d_winograd4_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),
     'raft_update_workspace_floats': (C.c_int64, [_I, _I, _I]),
     'raft_prepare_state_f32': (_I, [_P, _I, _I, _I, C.POINTER(State), _P]),
     'raft_gru_context_f32': (_I, [C.POINTER(BasicUpdateWeights), _I, _I, _I, C.POINTER(State), _P]),

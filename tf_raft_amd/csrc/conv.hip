@@ -189,9 +189,9 @@ extern "C" int raft_conv2d_winograd_f32(const float *a0, int lda0, int c0, const
     return raft_launch_conv_wino(a, act == RAFT_ACT_RELU ? EPI_RELU : EPI_LINEAR, (hipStream_t)stream);
 }
 
-extern "C" int raft_conv1d_winograd_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
-                                        const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
-                                        int npad, int nvalid, int act, float scale, float *out, int ldo, void *stream) {
+static int conv1d_winograd(int mo, const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                           const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
+                           int npad, int nvalid, int act, float scale, float *out, int ldo, void *stream) {
     RAFT_REQUIRE_PTR(a0);
     RAFT_REQUIRE_PTR(wp);
     RAFT_REQUIRE_PTR(bias);
@@ -205,16 +205,39 @@ extern "C" int raft_conv1d_winograd_f32(const float *a0, int lda0, int c0, const
     a.wp = wp; a.bias = bias; a.B = B; a.H = H; a.W = W;
     a.npad = npad; a.nvalid = nvalid; a.hid = 0; a.scale = scale;
     a.o0 = out; a.ldo0 = ldo;
-    return raft_launch_conv_wino1d(a, kh, kw, act == RAFT_ACT_RELU ? EPI_RELU : EPI_LINEAR, (hipStream_t)stream);
+    return raft_launch_conv_wino1d(a, kh, kw, act == RAFT_ACT_RELU ? EPI_RELU : EPI_LINEAR, (hipStream_t)stream, mo);
 }
 
-// The per-iteration SepConvGRU convolutions: direct halo kernel or 1-D Winograd F(2, 5) (conv_wino1d.h).
-// RAFT_GRU_WINO is a bit mask over {1: gru_zr1, 2: gru_q1, 4: gru_zr2, 8: gru_q2}; unset = RAFT_GRU_WINO_DEFAULT.
+extern "C" int raft_conv1d_winograd_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                                        const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
+                                        int npad, int nvalid, int act, float scale, float *out, int ldo, void *stream) {
+    return conv1d_winograd(2, a0, lda0, c0, a1, lda1, c1, wp, bias, B, H, W, kh, kw, npad, nvalid, act, scale, out, ldo, stream);
+}
+
+extern "C" int raft_conv1d_winograd4_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                                         const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
+                                         int npad, int nvalid, int act, float scale, float *out, int ldo, void *stream) {
+    return conv1d_winograd(4, a0, lda0, c0, a1, lda1, c1, wp, bias, B, H, W, kh, kw, npad, nvalid, act, scale, out, ldo, stream);
+}
+
+// The per-iteration SepConvGRU convolutions: direct halo kernel or 1-D Winograd F(2, 5) / F(4, 5) (conv_wino1d.h).
+// RAFT_GRU_WINO and RAFT_GRU_WINO4 are bit masks over {1: gru_zr1, 2: gru_q1, 4: gru_zr2, 8: gru_q2}; a layer runs
+// F(4, 5) if its WINO4 bit is set and the 8-tap weights were supplied, else F(2, 5) if its WINO bit is set and the
+// 6-tap weights were supplied, else the direct kernel.  Unset = the defaults below.
 constexpr int RAFT_GRU_WINO_DEFAULT = 15;
-static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int kh,
-                           int kw, int epi, hipStream_t s) {
+constexpr int RAFT_GRU_WINO4_DEFAULT = 15;
+static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weights &wino, const raft_conv_weights &wino4,
+                           int bit, ConvArgs a, int kh, int kw, int epi, hipStream_t s) {
     const char *e = getenv("RAFT_GRU_WINO");
     const int mask = e ? atoi(e) : RAFT_GRU_WINO_DEFAULT;
+    const char *e4 = getenv("RAFT_GRU_WINO4");
+    const int mask4 = e4 ? atoi(e4) : RAFT_GRU_WINO4_DEFAULT;
+    if ((mask4 & bit) && wino4.wp != nullptr && a.c0 % 32 == 0 && a.c1 % 32 == 0) {
+        a.wp = wino4.wp;
+        a.bias = wino4.bias;
+        a.npad = wino4.npad;
+        return raft_launch_conv_wino1d(a, kh, kw, epi, s, 4);
+    }
     if ((mask & bit) && wino.wp != nullptr) {
         a.wp = wino.wp;
         a.bias = wino.bias;
@@ -592,6 +615,8 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         const raft_conv_weights &wq = pass == 0 ? wts->gru_q1 : wts->gru_q2;
         const raft_conv_weights &wzr_w = pass == 0 ? wts->gru_zr1_w : wts->gru_zr2_w;
         const raft_conv_weights &wq_w = pass == 0 ? wts->gru_q1_w : wts->gru_q2_w;
+        const raft_conv_weights &wzr_w4 = pass == 0 ? wts->gru_zr1_w4 : wts->gru_zr2_w4;
+        const raft_conv_weights &wq_w4 = pass == 0 ? wts->gru_q1_w4 : wts->gru_q2_w4;
         const int kh = pass == 0 ? 1 : 5, kw = pass == 0 ? 5 : 1;
         const float *xm = st->x + CDIM;                      // [motion | flow]; the inp rows live in st->ctx
         const float *ctx = st->ctx + pass * 3 * HDIM;        // [z | r | q] context of this pass
@@ -599,14 +624,14 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
             ConvArgs a = conv_args(wzr, st->net, HDIM, HDIM, xm, XDIM, XDIM - CDIM, B, h, w, 2 * HDIM, zb, HDIM);
             a.hid = HDIM; a.o1 = rh; a.ldo1 = HDIM; a.e0 = st->net; a.lde0 = HDIM;
             a.init = ctx; a.ldi = CTX_LD;
-            RAFT_TRY(launch_gru_conv(wzr, wzr_w, pass == 0 ? 1 : 4, a, kh, kw, EPI_GRU_ZR, s));
+            RAFT_TRY(launch_gru_conv(wzr, wzr_w, wzr_w4, pass == 0 ? 1 : 4, a, kh, kw, EPI_GRU_ZR, s));
             RAFT_MARK();
         }
         {
             ConvArgs a = conv_args(wq, rh, HDIM, HDIM, xm, XDIM, XDIM - CDIM, B, h, w, HDIM, st->net, HDIM);
             a.e0 = st->net; a.lde0 = HDIM; a.e1 = zb; a.lde1 = HDIM;
             a.init = ctx + 2 * HDIM; a.ldi = CTX_LD;
-            RAFT_TRY(launch_gru_conv(wq, wq_w, pass == 0 ? 2 : 8, a, kh, kw, EPI_GRU_Q, s));
+            RAFT_TRY(launch_gru_conv(wq, wq_w, wq_w4, pass == 0 ? 2 : 8, a, kh, kw, EPI_GRU_Q, s));
             RAFT_MARK();
         }
     }

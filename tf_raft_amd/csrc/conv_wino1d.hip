@@ -1,15 +1,15 @@
-// 1-D Winograd F(2, 5) convolution launcher (kernel: conv_wino1d.h).
+// 1-D Winograd F(2, 5) / F(4, 5) convolution launcher (kernel: conv_wino1d.h).
 #include "conv_wino1d.h"
 
 constexpr bool RAFT_WINO1D_CK2_DEFAULT = true;   // 32 channels per barrier: +2-4 % on the GRU layers (profiles/r03u)
 
-template <int AXIS, int TNW, int CK, int TM>
+template <int AXIS, int TNW, int CK, int TM, int MO = 2>
 static int launch_wino1d(const ConvArgs &a, int epi, int grid, hipStream_t s) {
     switch (epi) {
-        case EPI_LINEAR: conv_wino1d_kernel<AXIS, TNW, EPI_LINEAR, CK, TM><<<grid, 256, 0, s>>>(a); break;
-        case EPI_RELU: conv_wino1d_kernel<AXIS, TNW, EPI_RELU, CK, TM><<<grid, 256, 0, s>>>(a); break;
-        case EPI_GRU_ZR: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_ZR, CK, TM><<<grid, 256, 0, s>>>(a); break;
-        case EPI_GRU_Q: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_Q, CK, TM><<<grid, 256, 0, s>>>(a); break;
+        case EPI_LINEAR: conv_wino1d_kernel<AXIS, TNW, EPI_LINEAR, CK, TM, MO><<<grid, 256, 0, s>>>(a); break;
+        case EPI_RELU: conv_wino1d_kernel<AXIS, TNW, EPI_RELU, CK, TM, MO><<<grid, 256, 0, s>>>(a); break;
+        case EPI_GRU_ZR: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_ZR, CK, TM, MO><<<grid, 256, 0, s>>>(a); break;
+        case EPI_GRU_Q: conv_wino1d_kernel<AXIS, TNW, EPI_GRU_Q, CK, TM, MO><<<grid, 256, 0, s>>>(a); break;
         default: return RAFT_E_UNSUPPORTED;
     }
     return raft_launch_status();
@@ -21,7 +21,9 @@ static int launch_wino1d_tm(const ConvArgs &a, int epi, int grid, int tnw, bool 
     return tnw == 2 ? launch_wino1d<AXIS, 2, 1, TM>(a, epi, grid, s) : launch_wino1d<AXIS, 1, 1, TM>(a, epi, grid, s);
 }
 
-int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s) {
+int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s, int mo) {
+    if (mo != 2 && mo != 4) return RAFT_E_UNSUPPORTED;
+    if (mo == 4 && (a.c0 % 32 || a.c1 % 32)) return RAFT_E_UNSUPPORTED;
     if (!((kh == 1 && kw == 5) || (kh == 5 && kw == 1))) return RAFT_E_UNSUPPORTED;
     if (a.c0 <= 0 || a.c0 % 16 || a.c1 < 0 || a.c1 % 16 || a.npad <= 0 || a.npad % 32) return RAFT_E_UNSUPPORTED;
     if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
@@ -33,7 +35,7 @@ int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStrea
         if (M * a.ldo0 * 4 >= lim || (a.o1 && M * a.ldo1 * 4 >= lim) || (a.e0 && M * a.lde0 * 4 >= lim) ||
             (a.e1 && M * a.lde1 * 4 >= lim) || (a.init && M * a.ldi * 4 >= lim))
             return RAFT_E_UNSUPPORTED;
-        if ((int64_t)6 * (a.c0 + a.c1) * a.npad * 4 >= lim) return RAFT_E_UNSUPPORTED;
+        if ((int64_t)(mo + 4) * (a.c0 + a.c1) * a.npad * 4 >= lim) return RAFT_E_UNSUPPORTED;
     }
     const int axis = kh == 5 ? 1 : 0;
     const char *e = getenv("RAFT_WINO_TNW");   // tuning / test overrides, read per call
@@ -48,6 +50,16 @@ int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStrea
     // 64-channel workgroups (a transformed input feeds two column blocks) wherever the channel count allows; full-height
     // tiles (TM = 2) when they still give about two workgroups per CU, half-height tiles otherwise (gru_q at B = 4:
     // 224 -> 448 workgroups)
+    if (mo == 4) {
+        // F(4, 5): a workgroup owns 2 rows x 64 columns (1x5) or 8 rows x 16 columns (5x1); 64-channel workgroups while
+        // that leaves about two per CU
+        const int tiles = axis == 0 ? a.B * ((a.H + 1) / 2) * ((a.W + 63) / 64) : a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
+        int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) >= 400) ? 2 : 1;
+        if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
+        const int grid = tiles * (a.npad / (32 * tnw));
+        if (axis == 0) return tnw == 2 ? launch_wino1d<0, 2, 2, 1, 4>(a, epi, grid, s) : launch_wino1d<0, 1, 2, 1, 4>(a, epi, grid, s);
+        return tnw == 2 ? launch_wino1d<1, 2, 2, 1, 4>(a, epi, grid, s) : launch_wino1d<1, 1, 2, 1, 4>(a, epi, grid, s);
+    }
     int tnw = a.npad % 64 == 0 ? 2 : 1;
     if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
     int tm = (int64_t)tiles_of(2) * (a.npad / (32 * tnw)) >= 400 ? 2 : 1;

@@ -79,8 +79,28 @@ WINO1D_BT = np.array([[1, 0, -5, 0, 4, 0], [0, -1, -1, 4, 4, 0], [0, 1, -1, -4, 
 WINO1D_AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 0.5, -0.5, 1]], dtype=np.float64)
 
 
-def winograd1d_kernel(kernel: np.ndarray) -> np.ndarray:
-    """(1, 5, Cin, Cout) or (5, 1, Cin, Cout) -> (6, 1, Cin, Cout): U[t] = sum_k G'[t, k] g[k], float64 then one rounding."""
+# 1-D Winograd F(4, 5), points {0, +-1, +-1/2, +-2, inf}; B^T rows rescaled by 4, 4, 4, 2, 2, 4, 4, 4 to integers
+# and G rows by the inverse (csrc/conv_wino1d.h, MO = 4)
+_WINO1D4_G = np.array([[-1, 0, 0, 0, 0],
+                       [-2 / 9, -2 / 9, -2 / 9, -2 / 9, -2 / 9],
+                       [-2 / 9, 2 / 9, -2 / 9, 2 / 9, -2 / 9],
+                       [32 / 45, 16 / 45, 8 / 45, 4 / 45, 2 / 45],
+                       [32 / 45, -16 / 45, 8 / 45, -4 / 45, 2 / 45],
+                       [1 / 90, 1 / 45, 2 / 45, 4 / 45, 8 / 45],
+                       [1 / 90, -1 / 45, 2 / 45, -4 / 45, 8 / 45],
+                       [0, 0, 0, 0, 1]], dtype=np.float64) / np.array([4, 4, 4, 2, 2, 4, 4, 4], dtype=np.float64)[:, None]
+WINO1D4_BT = np.array([[-4, 0, 21, 0, -21, 0, 4, 0], [0, 4, 4, -17, -17, 4, 4, 0], [0, -4, 4, 17, -17, -4, 4, 0],
+                       [0, 4, 8, -5, -10, 1, 2, 0], [0, -4, 8, 5, -10, -1, 2, 0], [0, 2, 1, -10, -5, 8, 4, 0],
+                       [0, -2, 1, 10, -5, -8, 4, 0], [0, -4, 0, 21, 0, -21, 0, 4]], dtype=np.float64)
+WINO1D4_AT = np.array([[1, 1, 1, 1, 1, 1, 1, 0], [0, 1, -1, 0.5, -0.5, 2, -2, 0],
+                       [0, 1, 1, 0.25, 0.25, 4, 4, 0], [0, 1, -1, 0.125, -0.125, 8, -8, 1]], dtype=np.float64)
+
+
+def winograd1d_kernel(kernel: np.ndarray, m: int = 2) -> np.ndarray:
+    """(1, 5, Cin, Cout) or (5, 1, Cin, Cout) -> (m + 4, 1, Cin, Cout): U[t] = sum_k G'[t, k] g[k], float64 then one
+    rounding.  m = 2: F(2, 5), m = 4: F(4, 5)."""
+    if m not in (2, 4):
+        raise ValueError(f'winograd1d_kernel: m must be 2 or 4, got {m}')
     k = np.asarray(kernel, dtype=np.float64)
     if k.shape[:2] == (1, 5):
         g = k[0]
@@ -88,13 +108,13 @@ def winograd1d_kernel(kernel: np.ndarray) -> np.ndarray:
         g = k[:, 0]
     else:
         raise ValueError(f'winograd1d_kernel expects a 1x5 or 5x1 kernel, got {k.shape[:2]}')
-    return np.einsum('tk,kio->tio', _WINO1D_G, g).astype(np.float32)[:, None]
+    return np.einsum('tk,kio->tio', _WINO1D_G if m == 2 else _WINO1D4_G, g).astype(np.float32)[:, None]
 
 
-def pack_conv_winograd1d(kernel: np.ndarray, bias: np.ndarray,
-                         sources: Sequence[Tuple[int, int]] = None) -> Tuple[np.ndarray, np.ndarray, int]:
-    """``pack_conv`` of the F(2, 5)-transformed kernel (6 taps), consumed by ``conv_wino1d_kernel``."""
-    return pack_conv(winograd1d_kernel(kernel), bias, sources)
+def pack_conv_winograd1d(kernel: np.ndarray, bias: np.ndarray, sources: Sequence[Tuple[int, int]] = None,
+                         m: int = 2) -> Tuple[np.ndarray, np.ndarray, int]:
+    """``pack_conv`` of the F(m, 5)-transformed kernel (m + 4 taps), consumed by ``conv_wino1d_kernel``."""
+    return pack_conv(winograd1d_kernel(kernel, m), bias, sources)
 
 
 def fuse_n(weights: Dict[str, np.ndarray], names: Sequence[str]):
@@ -124,18 +144,22 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     # SepConvGRU: the `inp` rows (128:256 of hx) of z / r / q go to the loop-invariant context
     # convolution gru_ctx{s} together with the biases; the per-iteration kernels keep [h | motion | flow]
     loop_rows = np.r_[0:128, 256:384]
-    ctx, gru_w = [], []
+    ctx, gru_w, gru_w4 = [], [], []
     for s in ('1', '2'):
         k, b = fuse_n(w, [f'{p}/gru/convz{s}', f'{p}/gru/convr{s}'])
         wp, bb, npad = pack_conv(k[:, :, loop_rows, :], np.zeros_like(b), [(128, 128), (128, 128)])
         out.append((f'gru_zr{s}', wp, bb, npad))
         wp, bb, npad = pack_conv_winograd1d(k[:, :, loop_rows, :], np.zeros_like(b), [(128, 128), (128, 128)])
         gru_w.append((f'gru_zr{s}_w', wp, bb, npad))
+        wp, bb, npad = pack_conv_winograd1d(k[:, :, loop_rows, :], np.zeros_like(b), [(128, 128), (128, 128)], m=4)
+        gru_w4.append((f'gru_zr{s}_w4', wp, bb, npad))
         kq, bq = w[f'{p}/gru/convq{s}/kernel'], w[f'{p}/gru/convq{s}/bias']
         wp, bb, npad = pack_conv(kq[:, :, loop_rows, :], np.zeros_like(bq), [(128, 128), (128, 128)])
         out.append((f'gru_q{s}', wp, bb, npad))
         wp, bb, npad = pack_conv_winograd1d(kq[:, :, loop_rows, :], np.zeros_like(bq), [(128, 128), (128, 128)])
         gru_w.append((f'gru_q{s}_w', wp, bb, npad))
+        wp, bb, npad = pack_conv_winograd1d(kq[:, :, loop_rows, :], np.zeros_like(bq), [(128, 128), (128, 128)], m=4)
+        gru_w4.append((f'gru_q{s}_w4', wp, bb, npad))
         kc = np.concatenate([k, kq], axis=3)[:, :, 128:256, :]
         wp, bb, npad = pack_conv(kc, np.concatenate([b, bq]))
         ctx.append((f'gru_ctx{s}', wp, bb, npad))
@@ -160,6 +184,9 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     # flow_head.conv1 alone (final-only prediction loop: the mask half of fh1_mask0 is skipped)
     wp, bb, npad = pack_conv_winograd(w[f'{p}/flow_head/conv1/kernel'], w[f'{p}/flow_head/conv1/bias'])
     out.append(('fh1_w', wp, bb, npad))
+    # F(4, 5)-transformed copies of the SepConvGRU convolutions
+    order4 = ['gru_zr1_w4', 'gru_q1_w4', 'gru_zr2_w4', 'gru_q2_w4']
+    out = out + sorted(gru_w4, key=lambda e: order4.index(e[0]))
     return out
 
 
