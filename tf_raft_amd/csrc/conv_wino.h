@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
         const bool ok = (hp < HP) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
         pix[i] = ok ? (b * p.H + yy) * p.W + xx : -1;
-        lds_off[i] = hp < HP ? hp * LDA + c4 * 4 : HP * LDA;
+        lds_off[i] = hp < HP ? hp * (LDA / 4) + c4 : HP * (LDA / 4);   // 16-byte units
     }
     f32x4 ra[NA], pre_sc, pre_sh;
     auto gload = [&](int c) {
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = pix[i] >= 0 ? fmaxf(fmaf(v[e], pre_sc[e], pre_sh[e]), 0.f) : 0.f;
             }
-            *(f32x4 *)(smem + buf * A_BUF + lds_off[i]) = v;
+            *(f32x4 *)(smem + buf * A_BUF + lds_off[i] * 4) = v;
         }
     };
 
@@ -241,6 +241,16 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     const __amdgpu_buffer_rsrc_t re1 = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(EPI == EPI_GRU_Q ? (const void *)p.e1 : (const void *)p.o0), 0,
         EPI == EPI_GRU_Q ? (int)((((long)M - 1) * p.lde1 + we) * 4) : 0, 0x00020000);
+    // Addresses: one lane base per tensor (pixel (yy, x0 + 8G), channel n; RAFT_OOB when the lane's channel takes no
+    // part) + a wave-uniform element offset in the instruction's scalar operand; elements outside the image (only in
+    // tiles cut by the border) get the out-of-range bit.
+    auto bstore = [](float v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, soff, 0);
+    };
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+    };
+    const bool interior = (y0 + TH <= p.H) & (x0 + TW <= p.W);   // wave-uniform
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
         const int n = n0 + (cg * TNW + j) * 16 + LR;
@@ -259,38 +269,38 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const f32x4 ya = (T[i][0] + T[i][1]) + T[i][2], yb = (T[i][1] - T[i][2]) - T[i][3];
-            const int yy = y0 + 2 * rb + i;
+            const int yy = y0 + 2 * rb + i, xb = x0 + 8 * G;    // the lane's tiles 4G + r: pixels xb + 2 r + jx of row yy
+            const unsigned pix0 = (unsigned)((b * p.H + yy) * p.W + xb);
+            unsigned dead[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jx = 0; jx < 2; ++jx)
+                    dead[r][jx] = (interior | ((yy < p.H) & (xb + 2 * r + jx < p.W))) ? 0u : RAFT_OOB;
+            const unsigned bo0 = (EPI == EPI_GRU_ZR ? (nok & isz) : nok) ? (pix0 * p.ldo0 + nh) * 4u : RAFT_OOB;
+            const unsigned bo1 = (EPI == EPI_GRU_ZR && nok && !isz) ? (pix0 * p.ldo1 + nh) * 4u : RAFT_OOB;
+            const unsigned be0 = (HAS_E0 && (EPI == EPI_GRU_ZR ? (nok & !isz) : nok)) ? (pix0 * p.lde0 + nh) * 4u : RAFT_OOB;
+            const unsigned be1 = (EPI == EPI_GRU_Q && nok) ? (pix0 * p.lde1 + n) * 4u : RAFT_OOB;
             float xv[4][2], zv[4][2];
             if (HAS_E0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int jx = 0; jx < 2; ++jx) {
-                        const int xx = x0 + 2 * (4 * G + r) + jx;
-                        const bool ok = nok & (yy < p.H) & (xx < p.W) & !(EPI == EPI_GRU_ZR && isz);
-                        const unsigned m = (unsigned)((b * p.H + yy) * p.W + xx);
-                        xv[r][jx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                                  re0, ok ? (int)((m * p.lde0 + nh) * 4u) : (int)RAFT_OOB, 0, 0));
-                        if (EPI == EPI_GRU_Q)
-                            zv[r][jx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                                      re1, ok ? (int)((m * p.lde1 + n) * 4u) : (int)RAFT_OOB, 0, 0));
+                        xv[r][jx] = bload(re0, be0 | dead[r][jx], (2 * r + jx) * p.lde0 * 4);
+                        if (EPI == EPI_GRU_Q) zv[r][jx] = bload(re1, be1 | dead[r][jx], (2 * r + jx) * p.lde1 * 4);
                     }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int xx = x0 + 2 * (4 * G + r);
 #pragma unroll
                 for (int jx = 0; jx < 2; ++jx) {
                     float v = (jx ? yb[r] : ya[r]) + bias;
-                    const bool mok = (yy < p.H) & (xx + jx < p.W);
-                    const unsigned mg = (unsigned)((b * p.H + yy) * p.W + xx + jx);
+                    const int so0 = (2 * r + jx) * p.ldo0 * 4;
                     if (EPI == EPI_GRU_ZR) {
                         const float g = raft_sigmoid(v);
-                        const bool ok = nok & mok;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), ro0,
-                                                              (ok & isz) ? (int)((mg * p.ldo0 + nh) * 4u) : (int)RAFT_OOB, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g * xv[r][jx]), ro1,
-                                                              (ok & !isz) ? (int)((mg * p.ldo1 + nh) * 4u) : (int)RAFT_OOB, 0, 0);
+                        bstore(g, ro0, bo0 | dead[r][jx], so0);
+                        bstore(g * xv[r][jx], ro1, bo1 | dead[r][jx], (2 * r + jx) * p.ldo1 * 4);
                         continue;
                     }
                     if (EPI == EPI_GRU_Q) {
@@ -301,14 +311,12 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                         if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
                         v *= p.scale;
                     }
-                    if (STATS && mok) {
+                    if (STATS && dead[r][jx] == 0u) {
                         s1 += v;
                         s2 = fmaf(v, v, s2);
                     }
-                    const unsigned m = (unsigned)((b * p.H + yy) * p.W + xx + jx);
                     if ((RAFT_WINO_ABL & 8) && v != 12345.678f) continue;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro0,
-                                                          (nok & mok) ? (int)((m * p.ldo0 + n) * 4u) : (int)RAFT_OOB, 0, 0);
+                    bstore(v, ro0, bo0 | dead[r][jx], so0);
                 }
             }
         }
