@@ -329,6 +329,24 @@ int raft_iterate_small_f32(const raft_small_update_weights *wts, const float *py
                            const int64_t *level_offsets, int B, int h, int w, int iters,
                            const raft_state *st, float *flow_up, void *stream);
 
+/* ------------------------------------------------------------------ evaluation metrics / loss */
+
+/* Reductions over flow predictions (reference tf_raft/losses/losses.py; the caller side of the forward pass:
+ * model.py:146-158 test_step, 126-144 train_step).  flow_gt / predictions: (npix, 2) fp32 with npix = B*H*W;
+ * valid: npix bytes (0 = invalid).  valid' = valid & (|flow_gt|_2 < max_flow).  Deterministic (no atomics);
+ * `workspace` = raft_metrics_workspace_doubles() doubles, 8-byte aligned; results are written to device memory. */
+int64_t raft_metrics_workspace_doubles(void);
+/* end_point_error (losses.py:24-43): out5 = {mean EPE over valid', rate EPE < 1, rate EPE < 3, rate EPE < 5,
+ * number of valid' pixels}; the means are NaN when no pixel is valid' (as tf.reduce_mean of an empty tensor). */
+int raft_flow_metrics_f32(const float *flow_gt, const unsigned char *valid, const float *flow_pred,
+                          int64_t npix, float max_flow, float *out5, double *workspace, void *stream);
+/* sequence_loss (losses.py:4-21): loss = sum_i gamma^(n-i-1) * mean over ALL 2*npix elements of valid' * |pred_i - gt|.
+ * Prediction i starts at preds + i * pred_stride floats (the flow_up buffer of raft_iterate_*: stride 2*npix);
+ * n_predictions <= 64. */
+int raft_sequence_loss_f32(const float *flow_gt, const unsigned char *valid, const float *preds,
+                           int64_t pred_stride, int n_predictions, int64_t npix, double gamma, float max_flow,
+                           float *loss_out, double *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -335,6 +335,24 @@ def test_product_path_fails_loudly_without_a_gpu():
         tf_raft_amd.RAFT()
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         coords_grid(1, 4, 4)
+    from tf_raft.losses.losses import end_point_error, sequence_loss   # the reference's import path
+    gt, valid = np.zeros((1, 2, 2, 2), np.float32), np.ones((1, 2, 2), bool)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        sequence_loss((gt, valid), [gt])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        end_point_error((gt, valid), gt)
+
+
+def test_running_mean_mirrors_keras_mean():
+    """tf.keras.metrics.Mean as the reference uses it (model.py:118-124, 168-170): mean of the fed scalars, 0 when empty."""
+    from tf_raft_amd.losses import Mean
+    m = Mean(name='epe')
+    assert m.name == 'epe' and m.result() == 0.0
+    for v in (1.0, 2.0, np.float32(6.0)):
+        m.update_state(v)
+    assert m.result() == 3.0 and m.count == 3
+    m.reset_states()
+    assert m.result() == 0.0 and m.count == 0
 
 
 def test_product_package_never_imports_the_oracle():

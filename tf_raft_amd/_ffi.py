@@ -68,6 +68,9 @@ _SIGNATURES = {
     'raft_upsample_convex_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'raft_upflow8_f32': (_I, [_P, _I, _I, _I, _P, _P]),
     'raft_stream_copy_f32': (_I, [_P, _P, C.c_int64, _P]),
+    'raft_metrics_workspace_doubles': (C.c_int64, []),
+    'raft_flow_metrics_f32': (_I, [_P, _P, _P, C.c_int64, C.c_float, _P, _P, _P]),
+    'raft_sequence_loss_f32': (_I, [_P, _P, _P, C.c_int64, _I, C.c_int64, C.c_double, C.c_float, _P, _P, _P]),
     'raft_conv2d_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I,
                              C.c_float, _P, _I, _P]),
     'raft_conv2d_winograd_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),

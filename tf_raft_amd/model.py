@@ -14,14 +14,16 @@ Execution: encoders on PyTorch-ROCm, then everything on hand-written HIP kernels
 (lookup -> update block -> coords update -> upsampling) enqueued by ONE ``raft_iterate_*`` call on
 the current HIP stream with no host synchronisation.  There is no CPU fallback.
 
-Out of scope (training plumbing of the reference, model.py:111-170): ``compile``, ``train_step``,
-``test_step``, ``reset_metrics``.  ``predict_step``, ``load_weights`` / ``save_weights`` (TensorFlow
-tensor-bundle checkpoints, read and written without TensorFlow) are provided.
+Callers of the forward pass (reference model.py:111-170): ``compile``, ``test_step`` (EPE / u1 / u3 / u5 of the final
+prediction against ground truth, reduced on the device: ``tf_raft_amd.losses``), ``predict_step``, ``reset_metrics``,
+``load_weights`` / ``save_weights`` (TensorFlow tensor-bundle checkpoints, read and written without TensorFlow) are
+provided.  ``train_step`` (backward pass + optimizer) is out of scope and raises ``NotImplementedError``.
 """
 from __future__ import annotations
 
 import ctypes as C
 import os
+from collections import OrderedDict
 from typing import Dict, Optional
 
 import numpy as np
@@ -238,6 +240,42 @@ class RAFT:
         if self.variant == 'raft' and self.overlap and not self.alternate_corr:
             return self._forward([image1, image2], training=False, final_only=True)
         return self([image1, image2], training=False)[-1]
+
+
+    # ---- evaluation plumbing (reference model.py:111-170)
+    def compile(self, optimizer=None, clip_norm=None, loss=None, epe=None, **kwargs):
+        """reference model.py:111-124.  ``loss`` / ``epe`` default to ``tf_raft_amd.losses.sequence_loss`` /
+        ``end_point_error``; ``optimizer`` and ``clip_norm`` are kept for the caller but unused (no train_step)."""
+        from . import losses
+        if kwargs:
+            raise TypeError(f'unexpected keyword arguments {sorted(kwargs)}')
+        self.optimizer = optimizer
+        self.clip_norm = clip_norm
+        self.loss = loss if loss is not None else losses.sequence_loss
+        self.epe = epe if epe is not None else losses.end_point_error
+        self.flow_metrics = OrderedDict((k, losses.Mean(name=k)) for k in ('loss', 'epe', 'u1', 'u3', 'u5'))
+
+    def train_step(self, data):
+        raise NotImplementedError('train_step (reference model.py:126-144: backward pass, gradient clipping, optimizer) '
+                                  'is outside the MI355X forward-prediction path; use test_step / predict_step')
+
+    def test_step(self, data):
+        """reference model.py:146-158: forward prediction, then EPE / u1 / u3 / u5 of ``flow_predictions[-1]`` against
+        ``(flow, valid)`` into the running means; returns ``{name: mean so far}`` (``loss`` is only fed by train_step).
+        Only the last prediction is consumed, so it is computed the ``predict_step`` way."""
+        if not hasattr(self, 'flow_metrics'):
+            raise RuntimeError('call compile() before test_step()')   # keras raises for an un-compiled model too
+        image1, image2, flow, valid = data
+        last = self.predict_step((image1, image2))
+        info = self.epe([flow, valid], last)
+        for k in ('epe', 'u1', 'u3', 'u5'):
+            self.flow_metrics[k].update_state(info[k])
+        return {k: m.result() for k, m in self.flow_metrics.items()}
+
+    def reset_metrics(self):
+        """reference model.py:168-170."""
+        for m in getattr(self, 'flow_metrics', {}).values():
+            m.reset_states()
 
 
 class SmallRAFT(RAFT):
