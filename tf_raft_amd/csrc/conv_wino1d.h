@@ -47,6 +47,13 @@
 
 #include "conv_mfma.h"
 
+// Diagnostics only (tools/ablate/wino1d_abl.hip): bit 1 = weight fragments fetched once, 2 = input transform (LDS reads)
+// once, 4 = no halo staging inside the loop, 8 = no epilogue loads and a single store, 16 = MFMAs of tap 0 only.
+// 0 in the library build.
+#ifndef RAFT_WINO1D_ABL
+#define RAFT_WINO1D_ABL 0
+#endif
+
 // CK = 16-channel chunks staged per barrier (1 or 2).  TM = row blocks per wave (2, or 1: half-height workgroup tiles
 // -- twice the workgroups for layers such as gru_q (N = 128) that otherwise leave under one workgroup per CU).
 template <int AXIS, int TNW, int EPI, int CK = 1, int TM = 2, int MO = 2>
@@ -194,10 +201,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
             const bool more_c = more || sub + 1 < CK;
             f32x4 V[TM][NT];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) transform(buf, sub, i, V[i]);
+            for (int i = 0; i < TM; ++i)
+                if (!(RAFT_WINO1D_ABL & 2) || (st == 0 && sub == 0)) transform(buf, sub, i, V[i]);
             if (sub == CK - 1) {
                 // every LDS read of this stage has been issued: stage the next one into the other buffer
-                if (more) {
+                if (more && !(RAFT_WINO1D_ABL & 4)) {
                     lstore(buf ^ 1);
                     if (st + 2 < nst) gload(st + 2);
                 }
@@ -205,11 +213,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (t + 2 < NT)
+                if (RAFT_WINO1D_ABL & 1) {
+                } else if (t + 2 < NT)
                     frag_b(c, t + 2, fb[(t + 2) % RING]);
                 else if (more_c)
                     frag_b(c + 1, t + 2 - NT, fb[(t + 2) % RING]);
                 __builtin_amdgcn_sched_barrier(0);   // keep the weight fetch two taps ahead (see conv_wino.h)
+                if ((RAFT_WINO1D_ABL & 16) && t != 0) continue;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -296,6 +306,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int jx = 0; jx < MO; ++jx) {
+                    if (RAFT_WINO1D_ABL & 8) {
+                        iv[r][jx] = hv[r][jx] = zv[r][jx] = 0.5f;
+                        continue;
+                    }
                     iv[r][jx] = bload(ri, bi | dead[r][jx], es(r, jx) * p.ldi * 4);
                     if (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) hv[r][jx] = bload(re0, be0 | dead[r][jx], es(r, jx) * p.lde0 * 4);
                     if (EPI == EPI_GRU_Q) zv[r][jx] = bload(re1, be1 | dead[r][jx], es(r, jx) * p.lde1 * 4);
@@ -306,6 +320,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
                 for (int jx = 0; jx < MO; ++jx) {
                     const float v = (y[jx][r] + iv[r][jx]) + bias;
                     const int so0 = es(r, jx) * p.ldo0 * 4;
+                    if ((RAFT_WINO1D_ABL & 8) && v != 12345.678f) continue;
                     if (EPI == EPI_LINEAR || EPI == EPI_RELU) {
                         bstore((EPI == EPI_RELU ? fmaxf(v, 0.f) : v) * p.scale, ro0, bo0 | dead[r][jx], so0);
                     } else if (EPI == EPI_GRU_ZR) {
