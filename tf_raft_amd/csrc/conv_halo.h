@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
             }
     }
     lstore(0);
-    __syncthreads();
+    raft_barrier_lds();
     if (nch > 1) gload(1);
     frag_a(0, 0, fa[0]);
     if constexpr (DEEP) {
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
                         lstore(P ^ 1);
                         if (c + 2 < nch) gload(c + 2);
                     }
-                    __syncthreads();
+                    raft_barrier_lds();
                 }
             }
         };
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(ConvArgs p) {
                     lstore(buf ^ 1);
                     if (c + 2 < nch) gload(c + 2);
                 }
-                __syncthreads();
+                raft_barrier_lds();
             }
         }
     }

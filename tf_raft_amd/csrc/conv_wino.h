@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     frag_b(0, 0, fb[0]);
     frag_b(0, 1, fb[1]);
     lstore(0);
-    __syncthreads();
+    raft_barrier_lds();
     if (nst > 1) gload(1);
     // patch rows: dA holds row 0, later row 3; dB row 2; dC row 1.  Every LDS read is issued one tap row ahead of its
     // use (row 1 under the MFMAs of tap row 0, row 3 under tap row 1, the NEXT chunk's rows 0 and 2 under tap row 3).
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                             lstore(buf ^ 1);
                             if (st + 2 < nst) gload(st + 2);
                         }
-                        __syncthreads();
+                        raft_barrier_lds();
                         if (more) {
                             patch_row(buf ^ 1, 0, 0, dA);
                             patch_row(buf ^ 1, 0, 2, dB);

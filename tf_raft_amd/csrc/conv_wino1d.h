@@ -54,6 +54,116 @@
 #define RAFT_WINO1D_ABL 0
 #endif
 
+// Epilogue shared by the kernels of this file: A^T m, bias / context addend, activation or GRU gate, stores.  Lane owns
+// channel n; register r of an accumulator is output group m = 4G + r of row block TM * rbp + i.
+template <int AXIS, int TNW, int EPI, int TM, int MO>
+__device__ __forceinline__ void wino1d_epilogue(const ConvArgs &p, f32x4 (&acc)[TM][MO + 4][TNW], int rbp, int cg, int G, int LR,
+                                                int b, int y0, int x0, int n0, int M) {
+    constexpr int TILE_H = AXIS == 0 ? 2 * TM : 2 * MO * TM, TILE_W = AXIS == 0 ? 16 * MO : 16;
+    const int w0 = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;          // valid columns of o0
+    const int w1 = (EPI == EPI_GRU_ZR) ? p.nvalid - p.hid : 0;      // valid columns of o1
+    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + w0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(w1 > 0 ? p.o1 : p.o0), 0, w1 > 0 ? (int)((((long)M - 1) * p.ldo1 + w1) * 4) : 0, 0x00020000);
+    const bool has_e0 = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q, has_e1 = EPI == EPI_GRU_Q;
+    const int we = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;
+    const __amdgpu_buffer_rsrc_t re0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_e0 ? (const void *)p.e0 : (const void *)p.o0), 0,
+        has_e0 ? (int)((((long)M - 1) * p.lde0 + we) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t re1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_e1 ? (const void *)p.e1 : (const void *)p.o0), 0,
+        has_e1 ? (int)((((long)M - 1) * p.lde1 + we) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.init ? (const void *)p.init : (const void *)p.o0), 0,
+        p.init ? (int)((((long)M - 1) * p.ldi + p.nvalid) * 4) : 0, 0x00020000);
+    // Addresses: one lane base per tensor (first pixel of the lane's groups, channel n; RAFT_OOB when the lane's channel
+    // takes no part) + a wave-uniform element offset in the instruction's scalar operand; elements outside the image
+    // (only in tiles cut by the border) get the out-of-range bit.  A null `init` has a zero-sized descriptor: loads give 0.
+    auto bstore = [](float v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, soff, 0);
+    };
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+    };
+    const bool interior = (y0 + TILE_H <= p.H) & (x0 + TILE_W <= p.W);   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rb = TM * rbp + i;
+        // the lane's 4 groups m = 4G + r start at pixel (yb, xb); element (r, jx) lies es(r, jx) pixels further
+        const int yb = AXIS == 0 ? y0 + rb : y0 + MO * rb;
+        const int xb = AXIS == 0 ? x0 + MO * 4 * G : x0 + 4 * G;
+        const unsigned pix0 = (unsigned)((b * p.H + yb) * p.W + xb);
+        unsigned dead[4][MO];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int jx = 0; jx < MO; ++jx) {
+                const int yy = AXIS == 0 ? yb : yb + jx;
+                const int xx = AXIS == 0 ? xb + MO * r + jx : xb + r;
+                dead[r][jx] = (interior | ((yy < p.H) & (xx < p.W))) ? 0u : RAFT_OOB;
+            }
+        auto es = [&](int r, int jx) { return AXIS == 0 ? MO * r + jx : jx * p.W + r; };
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const int n = n0 + (cg * TNW + j) * 16 + LR;
+            const bool nok = n < p.nvalid;
+            const float bias = p.bias[n];                         // bias has npad entries
+            const bool isz = n < p.hid;
+            const unsigned nh = (unsigned)((EPI == EPI_GRU_ZR && !isz) ? n - p.hid : n);
+            f32x4 y[MO];                                          // A^T m
+            if constexpr (MO == 2) {
+                y[0] = ((acc[i][0][j] + acc[i][1][j]) + (acc[i][2][j] + acc[i][3][j])) + acc[i][4][j];
+                y[1] = ((acc[i][1][j] - acc[i][2][j]) + 0.5f * (acc[i][3][j] - acc[i][4][j])) + acc[i][5][j];
+            } else {
+                const f32x4 s12 = acc[i][1][j] + acc[i][2][j], d12 = acc[i][1][j] - acc[i][2][j];
+                const f32x4 s34 = acc[i][3][j] + acc[i][4][j], d34 = acc[i][3][j] - acc[i][4][j];
+                const f32x4 s56 = acc[i][5][j] + acc[i][6][j], d56 = acc[i][5][j] - acc[i][6][j];
+                y[0] = (acc[i][0][j] + s12) + (s34 + s56);
+                y[1] = (d12 + 0.5f * d34) + 2.0f * d56;
+                y[2] = (s12 + 0.25f * s34) + 4.0f * s56;
+                y[3] = ((d12 + 0.125f * d34) + 8.0f * d56) + acc[i][7][j];
+            }
+            const unsigned bi = nok ? (pix0 * p.ldi + n) * 4u : RAFT_OOB;                        // init
+            const unsigned bo0 = (EPI == EPI_GRU_ZR ? (nok & isz) : nok) ? (pix0 * p.ldo0 + nh) * 4u : RAFT_OOB;
+            const unsigned bo1 = (EPI == EPI_GRU_ZR && nok && !isz) ? (pix0 * p.ldo1 + nh) * 4u : RAFT_OOB;
+            const unsigned be0 = (EPI == EPI_GRU_ZR ? (nok & !isz) : (EPI == EPI_GRU_Q && nok)) ? (pix0 * p.lde0 + nh) * 4u : RAFT_OOB;
+            const unsigned be1 = (EPI == EPI_GRU_Q && nok) ? (pix0 * p.lde1 + n) * 4u : RAFT_OOB;
+            float iv[4][MO], hv[4][MO], zv[4][MO];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jx = 0; jx < MO; ++jx) {
+                    if (RAFT_WINO1D_ABL & 8) {
+                        iv[r][jx] = hv[r][jx] = zv[r][jx] = 0.5f;
+                        continue;
+                    }
+                    iv[r][jx] = bload(ri, bi | dead[r][jx], es(r, jx) * p.ldi * 4);
+                    if (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) hv[r][jx] = bload(re0, be0 | dead[r][jx], es(r, jx) * p.lde0 * 4);
+                    if (EPI == EPI_GRU_Q) zv[r][jx] = bload(re1, be1 | dead[r][jx], es(r, jx) * p.lde1 * 4);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jx = 0; jx < MO; ++jx) {
+                    const float v = (y[jx][r] + iv[r][jx]) + bias;
+                    const int so0 = es(r, jx) * p.ldo0 * 4;
+                    if ((RAFT_WINO1D_ABL & 8) && v != 12345.678f) continue;
+                    if (EPI == EPI_LINEAR || EPI == EPI_RELU) {
+                        bstore((EPI == EPI_RELU ? fmaxf(v, 0.f) : v) * p.scale, ro0, bo0 | dead[r][jx], so0);
+                    } else if (EPI == EPI_GRU_ZR) {
+                        const float g = raft_sigmoid(v);
+                        bstore(g, ro0, bo0 | dead[r][jx], so0);
+                        bstore(g * hv[r][jx], ro1, bo1 | dead[r][jx], es(r, jx) * p.ldo1 * 4);
+                    } else {
+                        const float q = raft_tanh(v);
+                        bstore((1.0f - zv[r][jx]) * hv[r][jx] + zv[r][jx] * q, ro0, bo0 | dead[r][jx], so0);
+                    }
+                }
+        }
+    }
+}
+
 // CK = 16-channel chunks staged per barrier (1 or 2).  TM = row blocks per wave (2, or 1: half-height workgroup tiles
 // -- twice the workgroups for layers such as gru_q (N = 128) that otherwise leave under one workgroup per CU).
 template <int AXIS, int TNW, int EPI, int CK = 1, int TM = 2, int MO = 2>
@@ -190,7 +300,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
     frag_b(0, 0, fb[0]);
     frag_b(0, 1, fb[1]);
     lstore(0);
-    __syncthreads();
+    raft_barrier_lds();
     if (nst > 1) gload(1);
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
@@ -209,7 +319,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
                     lstore(buf ^ 1);
                     if (st + 2 < nst) gload(st + 2);
                 }
-                __syncthreads();
+                raft_barrier_lds();
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -231,109 +341,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
         }
     }
 
-    // ---- epilogue: lane owns channel n; register r of an accumulator is output group m = 4G + r of the row block
-    const int w0 = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;          // valid columns of o0
-    const int w1 = (EPI == EPI_GRU_ZR) ? p.nvalid - p.hid : 0;      // valid columns of o1
-    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + w0) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(w1 > 0 ? p.o1 : p.o0), 0, w1 > 0 ? (int)((((long)M - 1) * p.ldo1 + w1) * 4) : 0, 0x00020000);
-    const bool has_e0 = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q, has_e1 = EPI == EPI_GRU_Q;
-    const int we = (EPI == EPI_GRU_ZR) ? p.hid : p.nvalid;
-    const __amdgpu_buffer_rsrc_t re0 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(has_e0 ? (const void *)p.e0 : (const void *)p.o0), 0,
-        has_e0 ? (int)((((long)M - 1) * p.lde0 + we) * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t re1 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(has_e1 ? (const void *)p.e1 : (const void *)p.o0), 0,
-        has_e1 ? (int)((((long)M - 1) * p.lde1 + we) * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.init ? (const void *)p.init : (const void *)p.o0), 0,
-        p.init ? (int)((((long)M - 1) * p.ldi + p.nvalid) * 4) : 0, 0x00020000);
-    // Addresses: one lane base per tensor (first pixel of the lane's groups, channel n; RAFT_OOB when the lane's channel
-    // takes no part) + a wave-uniform element offset in the instruction's scalar operand; elements outside the image
-    // (only in tiles cut by the border) get the out-of-range bit.  A null `init` has a zero-sized descriptor: loads give 0.
-    auto bstore = [](float v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, soff, 0);
-    };
-    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
-    };
-    const bool interior = (y0 + TILE_H <= p.H) & (x0 + TILE_W <= p.W);   // wave-uniform
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int rb = TM * rbp + i;
-        // the lane's 4 groups m = 4G + r start at pixel (yb, xb); element (r, jx) lies es(r, jx) pixels further
-        const int yb = AXIS == 0 ? y0 + rb : y0 + MO * rb;
-        const int xb = AXIS == 0 ? x0 + MO * 4 * G : x0 + 4 * G;
-        const unsigned pix0 = (unsigned)((b * p.H + yb) * p.W + xb);
-        unsigned dead[4][MO];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int jx = 0; jx < MO; ++jx) {
-                const int yy = AXIS == 0 ? yb : yb + jx;
-                const int xx = AXIS == 0 ? xb + MO * r + jx : xb + r;
-                dead[r][jx] = (interior | ((yy < p.H) & (xx < p.W))) ? 0u : RAFT_OOB;
-            }
-        auto es = [&](int r, int jx) { return AXIS == 0 ? MO * r + jx : jx * p.W + r; };
-#pragma unroll
-        for (int j = 0; j < TNW; ++j) {
-            const int n = n0 + (cg * TNW + j) * 16 + LR;
-            const bool nok = n < p.nvalid;
-            const float bias = p.bias[n];                         // bias has npad entries
-            const bool isz = n < p.hid;
-            const unsigned nh = (unsigned)((EPI == EPI_GRU_ZR && !isz) ? n - p.hid : n);
-            f32x4 y[MO];                                          // A^T m
-            if constexpr (MO == 2) {
-                y[0] = ((acc[i][0][j] + acc[i][1][j]) + (acc[i][2][j] + acc[i][3][j])) + acc[i][4][j];
-                y[1] = ((acc[i][1][j] - acc[i][2][j]) + 0.5f * (acc[i][3][j] - acc[i][4][j])) + acc[i][5][j];
-            } else {
-                const f32x4 s12 = acc[i][1][j] + acc[i][2][j], d12 = acc[i][1][j] - acc[i][2][j];
-                const f32x4 s34 = acc[i][3][j] + acc[i][4][j], d34 = acc[i][3][j] - acc[i][4][j];
-                const f32x4 s56 = acc[i][5][j] + acc[i][6][j], d56 = acc[i][5][j] - acc[i][6][j];
-                y[0] = (acc[i][0][j] + s12) + (s34 + s56);
-                y[1] = (d12 + 0.5f * d34) + 2.0f * d56;
-                y[2] = (s12 + 0.25f * s34) + 4.0f * s56;
-                y[3] = ((d12 + 0.125f * d34) + 8.0f * d56) + acc[i][7][j];
-            }
-            const unsigned bi = nok ? (pix0 * p.ldi + n) * 4u : RAFT_OOB;                        // init
-            const unsigned bo0 = (EPI == EPI_GRU_ZR ? (nok & isz) : nok) ? (pix0 * p.ldo0 + nh) * 4u : RAFT_OOB;
-            const unsigned bo1 = (EPI == EPI_GRU_ZR && nok && !isz) ? (pix0 * p.ldo1 + nh) * 4u : RAFT_OOB;
-            const unsigned be0 = (EPI == EPI_GRU_ZR ? (nok & !isz) : (EPI == EPI_GRU_Q && nok)) ? (pix0 * p.lde0 + nh) * 4u : RAFT_OOB;
-            const unsigned be1 = (EPI == EPI_GRU_Q && nok) ? (pix0 * p.lde1 + n) * 4u : RAFT_OOB;
-            float iv[4][MO], hv[4][MO], zv[4][MO];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int jx = 0; jx < MO; ++jx) {
-                    if (RAFT_WINO1D_ABL & 8) {
-                        iv[r][jx] = hv[r][jx] = zv[r][jx] = 0.5f;
-                        continue;
-                    }
-                    iv[r][jx] = bload(ri, bi | dead[r][jx], es(r, jx) * p.ldi * 4);
-                    if (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) hv[r][jx] = bload(re0, be0 | dead[r][jx], es(r, jx) * p.lde0 * 4);
-                    if (EPI == EPI_GRU_Q) zv[r][jx] = bload(re1, be1 | dead[r][jx], es(r, jx) * p.lde1 * 4);
-                }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int jx = 0; jx < MO; ++jx) {
-                    const float v = (y[jx][r] + iv[r][jx]) + bias;
-                    const int so0 = es(r, jx) * p.ldo0 * 4;
-                    if ((RAFT_WINO1D_ABL & 8) && v != 12345.678f) continue;
-                    if (EPI == EPI_LINEAR || EPI == EPI_RELU) {
-                        bstore((EPI == EPI_RELU ? fmaxf(v, 0.f) : v) * p.scale, ro0, bo0 | dead[r][jx], so0);
-                    } else if (EPI == EPI_GRU_ZR) {
-                        const float g = raft_sigmoid(v);
-                        bstore(g, ro0, bo0 | dead[r][jx], so0);
-                        bstore(g * hv[r][jx], ro1, bo1 | dead[r][jx], es(r, jx) * p.ldo1 * 4);
-                    } else {
-                        const float q = raft_tanh(v);
-                        bstore((1.0f - zv[r][jx]) * hv[r][jx] + zv[r][jx] * q, ro0, bo0 | dead[r][jx], so0);
-                    }
-                }
-        }
-    }
+    wino1d_epilogue<AXIS, TNW, EPI, TM, MO>(p, acc, rbp, cg, G, LR, b, y0, x0, n0, M);
 }
 
 // launcher (conv_wino1d.hip): kh x kw = 1x5 or 5x1; mo = 2: F(2, 5), `a.wp` holds G' g packed as a 6-tap kernel; mo = 4:
