@@ -278,6 +278,35 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert typed.raft_error_string(0) == b'ok'
 
 
+def _header_struct_fields(name):
+    """Field names of `typedef struct name { ... } name;` in include/raft_hip.h, in declaration order."""
+    with open(os.path.join(ROOT, 'include', 'raft_hip.h')) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    body = re.search(r'typedef struct %s\s*\{(.*?)\}\s*%s\s*;' % (name, name), text, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(None, 1)[1] if not decl.startswith('const') else decl.split(None, 2)[2]
+        for n in names.split(','):
+            fields.append(re.sub(r'[\s\*]|\[.*?\]', '', n))
+    return fields
+
+
+@pytest.mark.parametrize('c_name,py_name', [('raft_conv_weights', 'ConvWeights'),
+                                            ('raft_basic_update_weights', 'BasicUpdateWeights'),
+                                            ('raft_small_update_weights', 'SmallUpdateWeights'),
+                                            ('raft_encoder_weights', 'EncoderWeights'),
+                                            ('raft_state', 'State')])
+def test_ctypes_structs_mirror_the_header_field_for_field(c_name, py_name):
+    """The ctypes mirrors in tf_raft_amd/_ffi.py declare the same fields in the same order as include/raft_hip.h
+    (appending a field to one side only would silently shift every later pointer)."""
+    want = _header_struct_fields(c_name)
+    got = [f[0] for f in getattr(_ffi, py_name)._fields_]
+    assert got == want
+
+
 def test_pyramid_layout_host_helper():
     lib = _ffi.load_library()
     off = (C.c_int64 * 5)()
