@@ -2,8 +2,8 @@
 
 Drop-in for the forward path of ``daigo0927/tf-raft`` (``tf_raft.model.RAFT`` / ``SmallRAFT``):
 Python host code -> ctypes -> ``libraft_hip.so`` (hand-written HIP kernels, C ABI in
-``include/raft_hip.h``); PyTorch-ROCm only owns device memory / streams and runs the encoder
-convolutions.  See DESIGN.md.
+``include/raft_hip.h``); PyTorch-ROCm only owns device memory, streams and ``torch.distributed``.
+See DESIGN.md.
 """
 from .model import RAFT, SmallRAFT  # noqa: F401
 

@@ -9,8 +9,8 @@ Same constructor and call signature as the reference (model.py:11, 68, 174, 190)
 the result is a Python list of ``iters_pred`` (``iters`` when ``training=True``) fp32 device
 tensors, ``[-1]`` the finest, each answering ``.numpy()`` like a TF eager tensor.
 
-Execution: encoders on PyTorch-ROCm, then everything on hand-written HIP kernels behind the C ABI
-(``include/raft_hip.h``): correlation volume build, and the whole recurrent loop
+Execution: everything runs on hand-written HIP kernels behind the C ABI (``include/raft_hip.h``): the two
+encoders (``raft_encoder_f32``), the correlation volume build, and the whole recurrent loop
 (lookup -> update block -> coords update -> upsampling) enqueued by ONE ``raft_iterate_*`` call on
 the current HIP stream with no host synchronisation.  There is no CPU fallback.
 
