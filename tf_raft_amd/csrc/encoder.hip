@@ -43,11 +43,25 @@ __global__ void __launch_bounds__(1024) in_finalize_kernel(const float *__restri
     double a = 0.0, q = 0.0;
     if (c < C) {
         const float2 *src = (const float2 *)part + ((int64_t)img * tiles) * npad + c;
-        for (int t = grp; t < tiles; t += 16) {
+        // four loads in flight per thread (the partial records are 56 .. 900 per image: a dependent chain of L2 round
+        // trips otherwise); fixed summation order, so the result stays deterministic
+        double a1 = 0.0, q1 = 0.0, a2 = 0.0, q2 = 0.0, a3 = 0.0, q3 = 0.0;
+        int t = grp;
+        for (; t + 48 < tiles; t += 64) {
+            const float2 v0 = src[(int64_t)t * npad], v1 = src[(int64_t)(t + 16) * npad];
+            const float2 v2 = src[(int64_t)(t + 32) * npad], v3 = src[(int64_t)(t + 48) * npad];
+            a += (double)v0.x; q += (double)v0.y;
+            a1 += (double)v1.x; q1 += (double)v1.y;
+            a2 += (double)v2.x; q2 += (double)v2.y;
+            a3 += (double)v3.x; q3 += (double)v3.y;
+        }
+        for (; t < tiles; t += 16) {
             const float2 v = src[(int64_t)t * npad];
             a += (double)v.x;
             q += (double)v.y;
         }
+        a = (a + a1) + (a2 + a3);
+        q = (q + q1) + (q2 + q3);
     }
     sh[0][grp][threadIdx.x & 63] = a;
     sh[1][grp][threadIdx.x & 63] = q;
