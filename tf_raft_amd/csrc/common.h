@@ -74,3 +74,21 @@ static inline int raft_make_geom(int h, int w, int levels, const int64_t *level_
     }
     return RAFT_OK;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_barrier + fence, and the release fence
+// waits for EVERY outstanding memory operation of the wave (s_waitcnt vmcnt(0)): the global loads the K loops keep in
+// flight across their barriers (next stage's halo tile, weight fragments a few taps ahead) would be drained at each
+// stage and re-issued behind the barrier, exposing an L2 round trip per stage.  Nothing in these kernels communicates
+// through global memory inside a workgroup, so the barrier only has to wait for the wave's own LDS operations
+// (lgkmcnt) -- the "memory" clobber keeps the compiler from moving LDS accesses across it.
+#ifndef RAFT_LDS_BARRIER
+#define RAFT_LDS_BARRIER 1
+#endif
+__device__ __forceinline__ void raft_barrier_lds() {
+#if RAFT_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+

@@ -80,23 +80,6 @@ __device__ __forceinline__ float raft_tanh(float x) {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_barrier + fence, and the release fence
-// waits for EVERY outstanding memory operation of the wave (s_waitcnt vmcnt(0)): the global loads the K loops keep in
-// flight across their barriers (next stage's halo tile, weight fragments a few taps ahead) would be drained at each
-// stage and re-issued behind the barrier, exposing an L2 round trip per stage.  Nothing in these kernels communicates
-// through global memory inside a workgroup, so the barrier only has to wait for the wave's own LDS operations
-// (lgkmcnt) -- the "memory" clobber keeps the compiler from moving LDS accesses across it.
-#ifndef RAFT_LDS_BARRIER
-#define RAFT_LDS_BARRIER 1
-#endif
-__device__ __forceinline__ void raft_barrier_lds() {
-#if RAFT_LDS_BARRIER
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
-
 __device__ __forceinline__ f32x4 raft_buffer_load_f4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0));
 }

@@ -146,7 +146,8 @@ struct CorrGemmArgs {
     PyramidGeom g;
     int64_t col_off[RAFT_MAX_LEVELS + 1];   // first column of each level inside T
     int N, T, C;
-    float sqrt_c;
+    float sqrt_c, rcp_sqrt_c;
+    int rcp_exact;   // sqrt(C) is a power of two
 };
 
 constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32, CG_LD = 36;
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
     const int nk = p.C / CG_BK;
     gload(0);
     lstore(0);
-    __syncthreads();
+    raft_barrier_lds();
     for (int s = 0; s < nk; ++s) {
         const int buf = s & 1;
         if (s + 1 < nk) gload((s + 1) * CG_BK);
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
         }
         if (s + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
+        raft_barrier_lds();
     }
 
     // epilogue: lane owns column n (a target position of some level), 16 rows (queries) per tile
@@ -240,7 +241,9 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.N) base[(int64_t)m * map] = acc[i][j][r] / p.sqrt_c;
+                // corr.py:161 divides by sqrt(C); for C a power of four (256, 64) the reciprocal is exact and the
+                // product is the same float without the division sequence
+                if (m < p.N) base[(int64_t)m * map] = p.rcp_exact ? acc[i][j][r] * p.rcp_sqrt_c : acc[i][j][r] / p.sqrt_c;
             }
         }
     }
@@ -276,6 +279,11 @@ extern "C" int raft_corr_build_f32(const float *fmap1, const float *fmap2, int B
     a.col_off[levels] = t;
     a.T = (int)t;
     a.sqrt_c = sqrtf((float)C);
+    a.rcp_sqrt_c = 1.0f / a.sqrt_c;
+    {
+        int e = 0;
+        a.rcp_exact = frexpf(a.sqrt_c, &e) == 0.5f;   // mantissa 0.5 <=> power of two: x / 2^k == x * 2^-k exactly
+    }
     dim3 grid(raft_ceil_div(a.T, CG_BN), raft_ceil_div(a.N, CG_BM), B);
     corr_gemm_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
     return raft_launch_status();
