@@ -11,10 +11,18 @@ random Keras-default weights); all 24 upsampled predictions are produced, as the
 Inputs are generated on the device before the timed region.  With N > 1 every rank runs its own
 batch (weak scaling) and the final predictions are all-gathered over RCCL inside the timed region.
 
+N = 1 runs BASELINE configs[1] (batch 4 on the GPU); N > 1 runs configs[2]'s per-GPU shape (batch 8 per GPU: 64 pairs
+on 8 GPUs) unless --batch says otherwise.
+
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  roofline            the dominant kernel (by accumulated time) with achieved / peak (algorithmic FLOPs; a layer on a
-                      Winograd kernel also reports the MFMA FLOPs it really issues: executed_tflops)
+  roofline            the dominant kernel (by accumulated time): achieved = the FLOPs the kernel EXECUTES on the MFMA
+                      pipe per launch / its HIP-event time, frac = achieved / 157.3 TF (<= 1 by construction).  A layer on
+                      a Winograd kernel executes fewer multiplies than the direct convolution it computes; the
+                      direct-convolution figure is kept as algorithmic_tflops / frac_algorithmic (may exceed 1)
   roofline_corr_lookup the HBM-bound lookup kernel the north star singles out
+  roofline_corr_build  the volume build: bound "mfma" (its GEMM) with the HBM write figure beside it
+  traffic             HBM bytes per launch from the in-loop B=8 PMC passes of profiles/pmc_traffic.json (tools/pmc_traffic.sh),
+                      scaled per pair to this run's batch
   stage_ms            per-kernel average milliseconds per launch (HIP events, instrumented replay)
   cpu_baseline        the CPU oracle (reference restatement, torch-CPU) timed on this box's host cores
 """
@@ -41,8 +49,8 @@ STAGES = ['corr_lookup', 'convc1', 'convc2', 'convf1', 'convf2', 'conv', 'gru_zr
 
 
 # Layers that run on a Winograd kernel execute fewer multiplies than the convolution they compute: F(2x2, 3x3) 16 per
-# 36 (conv_wino.h), F(2, 5) 6 per 10 and F(4, 5) 8 per 20 (conv_wino1d.h).  `achieved` below always counts the
-# ALGORITHMIC (direct convolution) FLOPs, so it can exceed the fp32 MFMA peak; `executed_tflops` divides by this factor.
+# 36 (conv_wino.h), F(2, 5) 6 per 10 and F(4, 5) 8 per 20 (conv_wino1d.h).  roofline.achieved counts the FLOPs EXECUTED on
+# the MFMA pipe (direct FLOPs / this factor), so frac <= 1; the direct-convolution figure is kept as algorithmic_tflops.
 WINOGRAD_ALGORITHMS = {2.25: 'Winograd F(2x2,3x3)', 10.0 / 6.0: 'Winograd F(2,5)', 2.5: 'Winograd F(4,5)'}
 
 
@@ -50,9 +58,10 @@ def winograd_layers():
     """{stage name: direct MACs / executed MACs} of the stages that are on a Winograd kernel under the current
     RAFT_CONV_WINO / RAFT_GRU_WINO / RAFT_GRU_WINO4 switches (defaults of csrc/conv.hip: 3x3 mask 13 = convc2 | conv |
     fh1_mask0, GRU masks 15: F(4, 5) where its bit is set, else F(2, 5))."""
-    m3 = int(os.environ.get('RAFT_CONV_WINO', '13'))
-    mg = int(os.environ.get('RAFT_GRU_WINO', '15'))
-    mg4 = int(os.environ.get('RAFT_GRU_WINO4', '15'))
+    from tf_raft_amd import _ffi
+    m3 = int(_ffi.get_option('RAFT_CONV_WINO') or 13)
+    mg = int(_ffi.get_option('RAFT_GRU_WINO') or 15)
+    mg4 = int(_ffi.get_option('RAFT_GRU_WINO4') or 15)
     on = {}
     for bit, name in ((1, 'convc2'), (2, 'convf2'), (4, 'conv'), (8, 'fh1_mask0')):
         if m3 & bit:
@@ -102,16 +111,24 @@ def measured_copy_gbs(device, lib, _dev, check, floats=1 << 28, reps=10):
     return 2.0 * 4.0 * floats * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md section
-    HBM: gfx950 tallies 128-byte requests at 64 bytes).  None when no pass covers the kernel."""
+def pmc_traffic(kernel, B):
+    """(HBM bytes per launch at batch B, source note) of `kernel` from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json, regenerated by tools/pmc_traffic.sh + tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
+    separate passes over the single-stream loop at B = 8 -- a 550 MB volume, larger than the 256 MiB Infinity Cache --
+    FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM: gfx950 tallies 128-byte requests at 64 bytes).  The pass's
+    per-launch bytes are scaled per pair to this run's batch.  (None, None) when no pass covers the kernel."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
             t = json.load(f).get(kernel)
     except (OSError, ValueError):
-        return None
-    return t
+        return None, None
+    if not t or not t.get('batch'):
+        return None, None
+    per_pair = t['hbm_bytes_per_launch'] / t['batch']
+    note = {'source': t.get('source'), 'pass_batch': t['batch'], 'in_loop': bool(t.get('in_loop')),
+            'hbm_bytes_per_pair': round(per_pair), 'algorithmic_bytes_per_pair': t.get('algorithmic_bytes_per_pair'),
+            'scaled_to_batch': B}
+    return int(round(per_pair * B)), note
 
 
 def main():
@@ -119,7 +136,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=4, help='image pairs per GPU per step')
+    ap.add_argument('--batch', type=int, default=None,
+                    help='image pairs per GPU per step (default: 4 on one GPU = BASELINE configs[1]; 8 per GPU on N > 1 '
+                         'GPUs = configs[2], 64 pairs on 8 GPUs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-runs', type=int, default=2)
     args = ap.parse_args()
@@ -143,7 +162,9 @@ def main():
     from tf_raft_amd.layers.corr import CorrBlock
     from tf_raft_amd.parallel import all_gather_batch
 
-    B = args.batch
+    B = args.batch if args.batch else (4 if world == 1 else 8)
+    cfg_name = 'BASELINE configs[1]' if (world == 1 and B == 4) else (
+        'BASELINE configs[2] per-GPU shape' if B == 8 else 'custom batch')
     wts = wm.init_weights('raft', seed=0)
     model = tf_raft_amd.RAFT(iters_pred=ITERS, weights=wts)
     gen = torch.Generator(device=device)
@@ -182,8 +203,9 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'RAFT forward, batch {B} per GPU at {H}x{W}, iters_pred={ITERS}, all {ITERS} '
-                               'upsampled predictions, random Keras-default weights (BASELINE configs[1])',
+        'config': {'workload': f'RAFT forward {cfg_name}: batch {B}/GPU {H}x{W} iters_pred={ITERS} random weights',
+                   'detail': f'all {ITERS} upsampled predictions produced per pair, Keras-default random weights, inputs '
+                             'resident in HBM',
                    'pairs_per_gpu': B, 'global_batch': world * B, 'parallelism': f'dp{world}',
                    'collective': 'all_gather(flow_predictions[-1]) over RCCL' if world > 1 else 'none'},
     }
@@ -200,6 +222,16 @@ def main():
             model.predict_step((img1, img2))
         torch.cuda.synchronize()
         result['predict_step_pairs_per_s'] = round(B * n / (time.perf_counter() - t0), 3)
+        # ---------------- informational: the reference's canonical call shape (README.md:98-103), ONE (1,448,512,3) pair
+        for _ in range(2):
+            model([img1[:1], img2[:1]], training=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            model([img1[:1], img2[:1]], training=False)
+        torch.cuda.synchronize()
+        result['batch1_ms_per_pair'] = round(1e3 * (time.perf_counter() - t0) / n, 3)
+        result['batch1_pairs_per_s'] = round(n / (time.perf_counter() - t0), 3)
 
     if rank == 0:
         # ---------------- instrumented replay: per-kernel HIP-event timing on the launch stream
@@ -238,26 +270,24 @@ def main():
         copy_gbs = measured_copy_gbs(device, _dev.lib(), _dev, _ffi.check)
         result['hbm_copy_gbs_measured'] = round(copy_gbs, 1)
 
-        def traffic_of(name):
-            t = pmc_traffic(name)
-            if not t or t.get('batch') != B:
-                return None, None
-            return t['hbm_bytes_per_launch'], t
+        wl = winograd_layers()
         if dom in flops:
-            ach = flops[dom] / (stage_ms[dom] * 1e-3) / 1e12
-            tr, note = traffic_of(dom)
+            ratio = wl.get(dom, 1.0)                          # direct MACs / MACs issued on the MFMA pipe
+            alg = flops[dom] / (stage_ms[dom] * 1e-3) / 1e12
+            ach = alg / ratio
+            tr, note = pmc_traffic(dom, B)
             roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': tr,
-                    'flops_per_launch': flops[dom], 'ms_per_launch': stage_ms[dom], 'traffic_source': note}
-            if dom in winograd_layers():
-                ratio = winograd_layers()[dom]
-                roof['algorithm'] = WINOGRAD_ALGORITHMS[ratio] + \
-                    ': achieved counts the direct convolution FLOPs (the algorithmic figure), executed_tflops the MFMA FLOPs issued'
-                roof['executed_tflops'] = round(ach / ratio, 2)
-                roof['frac_executed'] = round(ach / ratio / PEAK_FP32_MFMA_TFLOPS, 4)
+                    'flops_per_launch': flops[dom] / ratio, 'ms_per_launch': stage_ms[dom], 'traffic_source': note,
+                    'flops_counted': 'executed on the MFMA pipe'}
+            if ratio != 1.0:
+                roof['algorithm'] = WINOGRAD_ALGORITHMS[ratio]
+                roof['direct_conv_flops_per_launch'] = flops[dom]
+                roof['algorithmic_tflops'] = round(alg, 2)    # direct-convolution FLOPs / time: may exceed the peak
+                roof['frac_algorithmic'] = round(alg / PEAK_FP32_MFMA_TFLOPS, 4)
         else:
             ach = bytes_[dom] / (stage_ms[dom] * 1e-3) / 1e9
-            tr, note = traffic_of(dom)
+            tr, note = pmc_traffic(dom, B)
             roof = {'kernel': dom, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': tr,
                     'bytes_per_launch': bytes_[dom], 'ms_per_launch': stage_ms[dom], 'traffic_source': note}
@@ -266,23 +296,29 @@ def main():
         # 8 TB/s datasheet peak (frac) and against this box's measured copy bandwidth (frac_of_measured_copy)
         for name in ('corr_lookup', 'upsample_convex'):
             gbs = bytes_[name] / (stage_ms[name] * 1e-3) / 1e9
-            tr, note = traffic_of(name)
+            tr, note = pmc_traffic(name, B)
             result['roofline_' + name] = {
                 'kernel': name, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                 'frac': round(gbs / PEAK_HBM_GBS, 4), 'frac_of_measured_copy': round(gbs / copy_gbs, 4),
                 'traffic': tr, 'bytes_per_launch': bytes_[name], 'ms_per_launch': stage_ms[name],
                 'traffic_source': note}
-        build_bytes = B * (2 * h * w * 256 * 4) + 4 * (corr._off[4])     # fmaps read + tiled pyramid written
-        gbs = build_bytes / (pre_ms['corr_build'] * 1e-3) / 1e9
+        # corr_build = pooled-fmap2 pyramid (2 small launches) + ONE fp32-MFMA NT GEMM fmap1 . pyramid^T whose epilogue
+        # writes all 4 levels.  Its floor is the GEMM (real FLOPs: every stored correlation value is a C-long dot
+        # product), the HBM write of the volume sits below it -- both are reported, bound = "mfma".
+        n_vals = sum((h >> l) * (w >> l) for l in range(4)) * h * w * B        # stored correlation values, 4 levels
+        build_flops = 2.0 * 256 * n_vals
+        build_bytes = B * (2 * h * w * 256 * 4) + 4 * (corr._off[4])           # fmaps read + tiled pyramid written
+        bms = pre_ms['corr_build'] * 1e-3
+        tr, note = pmc_traffic('corr_build', B)
         result['roofline_corr_build'] = {
-            'kernel': 'corr_build (fmap pyramid + corr_gemm)', 'bound': 'hbm', 'achieved': round(gbs, 1),
-            'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-            'frac_of_measured_copy': round(gbs / copy_gbs, 4), 'traffic': None, 'bytes_per_launch': build_bytes,
-            'ms_per_launch': round(pre_ms['corr_build'], 4),
-            'note': 'fp32-MFMA GEMM: 26.5 GFLOP at B=4 bound it at >= 0.17 ms (157.3 TF), below the HBM-write bound'}
+            'kernel': 'corr_build (fmap2 pyramid + corr_gemm)', 'bound': 'mfma',
+            'achieved': round(build_flops / bms / 1e12, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(build_flops / bms / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': tr, 'traffic_source': note,
+            'flops_per_launch': build_flops, 'ms_per_launch': round(pre_ms['corr_build'], 4),
+            'hbm_gbs': round(build_bytes / bms / 1e9, 1), 'hbm_frac': round(build_bytes / bms / 1e9 / PEAK_HBM_GBS, 4),
+            'hbm_frac_of_measured_copy': round(build_bytes / bms / 1e9 / copy_gbs, 4), 'bytes_per_launch': build_bytes}
         mfma_ms = sum(stage_ms[k] for k in flops)
         result['update_block_tflops'] = round(sum(flops.values()) / (mfma_ms * 1e-3) / 1e12, 2)
-        wl = winograd_layers()
         result['update_block_executed_tflops'] = round(
             sum(v / wl.get(k, 1.0) for k, v in flops.items())
             / (mfma_ms * 1e-3) / 1e12, 2)

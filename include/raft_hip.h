@@ -11,10 +11,38 @@
  *   - plain C: raw DEVICE pointers, explicit sizes, no torch / C++ types;
  *   - all tensors are fp32, NHWC (channels contiguous), exactly the reference's layouts;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only
- *     enqueue work, they never synchronise and never allocate;
+ *     enqueue work, they never synchronise and never allocate.  Two documented exceptions:
+ *     raft_loop_ctx_create / _destroy (the caller-owned context of the three-stream loops: 4 HIP
+ *     events + a cache of instantiated hipGraphs) and the bench-only raft_iterate_basic_timed_f32;
  *   - return value: RAFT_OK (0), a negative RAFT_E_* argument error, or a positive
  *     hipError_t from the launch; no exception or abort crosses the ABI;
- *   - the library is stateless and re-entrant (ordering only through `stream`).
+ *   - the library keeps no per-call state and is re-entrant (ordering only through `stream`).  Its
+ *     only process-global state is the table of tuning switches below (raft_set_option).
+ *
+ * Tuning switches (tests, A/B timing, ablation -- never needed for correct results; every setting
+ * computes the same function within the per-kernel tolerances).  Each is an integer with a built-in
+ * default; the table is initialised ONCE from the environment variables of the same names when the
+ * library is loaded and is changed afterwards only through raft_set_option -- the launch path reads
+ * an atomic, it never calls getenv:
+ *   RAFT_CONV_TILE      "<code>" or "<npad>:<taps>:<code>,...": tile of the direct convolution kernels
+ *                       (0..5 legacy (tap, chunk)-stepped tiles; 100 + 10*TH + TN halo tiles, TH in {4,7,8})
+ *   RAFT_CONV_DEEP      0/1  deep weight prefetch of the single-column-block halo tiles          (default 1)
+ *   RAFT_CONV_WINO      bit mask {1 convc2, 2 convf2, 4 conv, 8 fh1_mask0}: layers on the F(2x2,3x3) kernel (13)
+ *   RAFT_SMALL_WINO     bit mask {1 conv, 2 gru_zr, 4 gru_q, 8 fh1} of the SmallUpdateBlock      (default 15)
+ *   RAFT_GRU_WINO       bit mask {1 zr1, 2 q1, 4 zr2, 8 q2}: SepConvGRU layers on F(2,5)         (default 15)
+ *   RAFT_GRU_WINO4      the same mask for F(4,5), preferred where both bits are set              (default 15)
+ *   RAFT_WINO_TNW       1/2  32- or 64-channel workgroups of the Winograd kernels                (default: by grid size)
+ *   RAFT_WINO_SB        0/1  pinned weight prefetch of the F(2x2,3x3) kernel                      (default: by grid size)
+ *   RAFT_WINO_CK        1/2  16 or 32 channels per barrier                                       (default: by grid size)
+ *   RAFT_WINO1D_TM      1/2  half- / full-height F(2,5) tiles                                    (default: by grid size)
+ *   RAFT_ENC_TILE       "<th><tn>" halo tile of the encoder convolutions, e.g. 72                (default: by map height)
+ *   RAFT_ENC_WINO       0/1  encoder ResBlock 3x3 layers on the F(2x2,3x3) kernel                 (default 1)
+ *   RAFT_LOOKUP_KERNEL  0 strip kernel, 1 pair kernel (csrc/corr.hip)                            (default: see corr.hip)
+ *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
+ *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
+ *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x4 query blocks on MFMA         (default 1)
+ *   RAFT_LOOP_GRAPH     0/1  three-stream loops replayed as one hipGraph launch                  (default: 1 up to
+ *                       B*h*w = 7168 pixels, 0 above)
  */
 #ifndef RAFT_HIP_H_
 #define RAFT_HIP_H_
@@ -26,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 101          /* 0.1.1 */
+#define RAFT_HIP_VERSION 200          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -40,6 +68,13 @@ enum {
 int raft_version(void);
 /* Human-readable message for a return code (RAFT_E_* or hipError_t). */
 const char *raft_error_string(int rc);
+
+/* Tuning switches (table above).  value: decimal text (RAFT_CONV_TILE: its rule list); "" = unset (built-in default);
+ * NULL = back to the load-time (environment) state.  RAFT_E_UNSUPPORTED for an unknown name.  Thread-safe; takes effect
+ * for launches enqueued after the call. */
+int raft_set_option(const char *name, const char *value);
+/* Current value as text into buf ("" while unset). */
+int raft_get_option(const char *name, char *buf, size_t len);
 
 /* CRC-32C (Castagnoli, reflected 0x1EDC6F41) of `n` bytes, continuing from `crc` (0 to start).
  * Host-only.  The checksum of the TensorFlow tensor-bundle checkpoint files the reference
@@ -239,26 +274,42 @@ int raft_iterate_basic_f32(const raft_basic_update_weights *wts, const float *py
                            const int64_t *level_offsets, int B, int h, int w, int iters,
                            const raft_state *st, float *flow_up, void *stream);
 
+/* Caller-owned context of the three-stream loops below: the four cross-stream events of the schedule and a cache of up
+ * to four instantiated hipGraphs of whole prediction loops.  Create once per model / thread on the device the loops run
+ * on (the only entry point that allocates), pass to every raft_iterate_basic_{overlap,ondemand,final}_f32 call, destroy
+ * after the last loop has drained.  Not thread-safe: one context per launching thread. */
+typedef struct raft_loop_ctx raft_loop_ctx;
+int raft_loop_ctx_create(raft_loop_ctx **ctx);
+int raft_loop_ctx_destroy(raft_loop_ctx *ctx);
+
 /* The same loop scheduled on three streams: the flow branch (convf1, convf2) and the mask branch (mask2,
  * convex upsample) run on the caller-owned side streams aux0 / aux1 next to the main chain on `stream`,
  * ordered by events; everything is joined back into `stream` before the call returns (it still only
- * enqueues).  Results are identical to raft_iterate_basic_f32. */
+ * enqueues).  Results are identical to raft_iterate_basic_f32.
+ * With RAFT_LOOP_GRAPH on (default for small batches) the first call with a given set of arguments (pointers, sizes,
+ * streams) captures these launches into a hipGraph kept in `ctx`; later calls with the same arguments replay it with ONE
+ * hipGraphLaunch on `stream` -- the reference's canonical (1,448,512,3) call is bound by the host's ~350 launches + ~100
+ * event operations otherwise.  A non-NULL `stream` is required for that (the legacy default stream cannot be captured;
+ * the plain launches are used on it). */
 int raft_iterate_basic_overlap_f32(const raft_basic_update_weights *wts, const float *pyr,
                                    const int64_t *level_offsets, int B, int h, int w, int iters,
-                                   const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1);
+                                   const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1,
+                                   raft_loop_ctx *ctx);
 
 /* The three-stream loop with the volume-free correlation (BASELINE config 4, no reference code: README.md:109):
  * fmap1 (B, h, w, C) and fmap2_pyr (raft_fmap_pyramid_f32) replace the stored pyramid. */
 int raft_iterate_basic_ondemand_f32(const raft_basic_update_weights *wts, const float *fmap1,
                                     const float *fmap2_pyr, int C, int B, int h, int w, int iters,
-                                    const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1);
+                                    const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1,
+                                    raft_loop_ctx *ctx);
 
 /* The three-stream loop for callers that want flow_predictions[-1] only (reference model.py:160-166, predict_step):
  * mask head + convex upsampling run in the last iteration only; flow_up_last: (B, 8h, 8w, 2).  The recurrence is launch
  * for launch that of raft_iterate_basic_overlap_f32, so the result equals its last prediction.  Needs wts->fh1_w. */
 int raft_iterate_basic_final_f32(const raft_basic_update_weights *wts, const float *pyr,
                                  const int64_t *level_offsets, int B, int h, int w, int iters,
-                                 const raft_state *st, float *flow_up_last, void *stream, void *aux0, void *aux1);
+                                 const raft_state *st, float *flow_up_last, void *stream, void *aux0, void *aux1,
+                                 raft_loop_ctx *ctx);
 
 /* Profiling twin of raft_iterate_basic_f32 (bench.py only): the same launches with a HIP event
  * recorded on `stream` after every kernel; synchronises the stream and accumulates the elapsed

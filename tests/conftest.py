@@ -38,3 +38,28 @@ def report(name, **vals):
     """Print measured errors so that `pytest -rA` / `-s` logs carry the numbers, not just PASS."""
     print('[parity] ' + name + ' ' + ' '.join(f'{k}={v:.3e}' if isinstance(v, float) else f'{k}={v}'
                                              for k, v in vals.items()))
+
+
+class _RaftOptions:
+    """Tuning switches of the library for the duration of one test (include/raft_hip.h: raft_set_option)."""
+
+    def __init__(self):
+        self._touched = []
+
+    def set(self, name, value):
+        from tf_raft_amd import _ffi
+        _ffi.set_option(name, value)
+        self._touched.append(name)
+
+    def restore(self):
+        from tf_raft_amd import _ffi
+        for name in self._touched:
+            _ffi.set_option(name, None)          # back to the load-time (environment) state
+        self._touched = []
+
+
+@pytest.fixture
+def raft_opt():
+    o = _RaftOptions()
+    yield o
+    o.restore()

@@ -90,3 +90,11 @@ def test_single_process_passthrough():
     assert all_gather_batch(t, 3) is t
     out = predict_sharded(lambda inp: [inp[0] * 2, inp[0] * 3], t, t)
     np.testing.assert_array_equal(out.numpy(), (t * 3).numpy())
+
+
+def test_empty_global_batch_is_rejected():
+    """An empty GLOBAL batch has no prediction to return (individual ranks may still get an empty shard)."""
+    import torch
+    from tf_raft_amd.parallel import predict_sharded
+    with pytest.raises(ValueError):
+        predict_sharded(lambda xs: [xs[0]], torch.zeros((0, 8, 8, 3)), torch.zeros((0, 8, 8, 3)))

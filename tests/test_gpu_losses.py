@@ -177,3 +177,24 @@ def test_end_point_error_metric_and_test_step(rng):
     assert all(m.count == 0 for m in model.flow_metrics.values())
     with pytest.raises(NotImplementedError):
         model.train_step((None, None, None, None))
+
+
+def test_sequence_loss_multiplies_by_the_mask_like_the_reference(rng):
+    """reference losses.py:14-19: ``mean(valid * |pred - gt|)`` -- the mask MULTIPLIES, so a NaN / Inf prediction at a
+    masked pixel still poisons the loss (0 * NaN = NaN), while end_point_error (losses.py:32, boolean selection
+    ``epe[valid]``) ignores it.  Both behaviours are the reference's and both are reproduced."""
+    from oracle import losses as oracle
+    from tf_raft_amd import losses
+    flow_gt, valid, preds = _random_case(rng, (1, 16, 24), 3, big=False)
+    valid[0, 3, 5] = False
+    clean = float(losses.sequence_loss((flow_gt, valid), preds))
+    assert np.isfinite(clean)
+    np.testing.assert_allclose(clean, oracle.sequence_loss((flow_gt, valid), preds), rtol=1e-5)
+    bad = [p.copy() for p in preds]
+    bad[1][0, 3, 5, 0] = np.nan                              # masked pixel
+    assert np.isnan(float(losses.sequence_loss((flow_gt, valid), bad)))
+    assert np.isnan(oracle.sequence_loss((flow_gt, valid), bad))
+    bad[1][0, 3, 5, 0] = np.inf
+    assert np.isnan(float(losses.sequence_loss((flow_gt, valid), bad)))        # 0 * inf
+    info = losses.end_point_error([flow_gt, valid], bad[1])
+    assert np.isfinite(float(info['epe']))                   # selection, not multiplication

@@ -61,9 +61,8 @@ def test_output_is_list_of_iters_flows(cls_name):
         assert tuple(flow.shape) == (4, 64, 96, 2)
         assert np.isfinite(flow.numpy()).all()
     last = model.predict_step((image1, image2))
-    # not bit-equal across calls: MIOpen may pick a different convolution solver for the encoders
-    # on a repeated shape; the HIP loop itself is deterministic (test_hip_loop_is_deterministic)
-    np.testing.assert_allclose(last.numpy(), out[-1].numpy(), atol=1e-3)
+    # encoders and loop are deterministic HIP kernels: predict_step (final-only loop for RAFT) is bit-equal to call()[-1]
+    np.testing.assert_array_equal(last.numpy(), out[-1].numpy())
 
 
 def test_predict_step_final_only_loop_equals_last_prediction():
@@ -140,14 +139,17 @@ def test_tf_checkpoint_round_trip_through_the_model(tmp_path, variant):
 
 
 # ------------------------------------------------------------------ encoders
-@pytest.mark.parametrize('variant,H,W', [('raft', 128, 160), ('small', 96, 128)])
-def test_encoders_match_oracle(variant, H, W):
+@pytest.mark.parametrize('variant,H,W,B', [('raft', 128, 160, 2), ('small', 96, 128, 2), ('raft', 448, 512, 4),
+                                           ('small', 448, 512, 1)])
+def test_encoders_match_oracle(variant, H, W, B):
+    """fnet / cnet against the float64 oracle; (raft, 448x512, B=4) is the benchmarked configuration (its tile choices
+    depend on B and on the map size)."""
     import oracle
     from oracle.layers import W as OW, encoder
     import tf_raft_amd
     from tf_raft_amd import weights as wm
     wts = wm.init_weights(variant, seed=5, perturb=True)
-    i1, i2 = _images(2, 2, H, W)
+    i1, i2 = _images(2, B, H, W)
     model = (tf_raft_amd.RAFT if variant == 'raft' else tf_raft_amd.SmallRAFT)(weights=wts, iters_pred=1)
     x1 = torch.as_tensor(2 * (i1 / 255.0) - 1.0)
     x2 = torch.as_tensor(2 * (i2 / 255.0) - 1.0)
@@ -158,7 +160,7 @@ def test_encoders_match_oracle(variant, H, W):
     rc = encoder(ow, 'cnet', x1.double())
     for name, g, r in (('fmap1', f1, r1), ('fmap2', f2, r2), ('cnet', c, rc)):
         err = float(np.abs(_np(g) - r.numpy()).max())
-        report(f'encoder {variant} {name}', max_abs_vs_f64=err, scale=float(r.abs().max()))
+        report(f'encoder {variant} {H}x{W} B={B} {name}', max_abs_vs_f64=err, scale=float(r.abs().max()))
         assert err < 1e-4 * max(1.0, float(r.abs().max()))
     del oracle
 
@@ -187,6 +189,88 @@ def test_free_running_parity_small_inputs(variant, H, W, iters, seed):
     assert horizon, 'fixture says this case is ill conditioned from the start'
     for i in horizon:
         assert errs[i] <= TOL, (i, errs[i])
+
+
+# ------------------------------------------------------------------ the north-star sentence itself
+def _conditioned_case(variant, H, W, seed, B=1):
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_conditioning import case_inputs
+    return case_inputs(variant, H, W, seed, 'conditioned', B=B)
+
+
+def _assert_oracle_is_well_conditioned(key):
+    with open(os.path.join(GOLDEN, 'conditioning.json')) as f:
+        cond = json.load(f)[key]
+    assert max(cond['epe32v64']) <= 2e-4, 'fixture: the oracle itself is ill conditioned on this case'
+    return cond
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+@pytest.mark.parametrize('variant', ['raft', 'small'])
+def test_north_star_free_running_final_prediction(variant, seed):
+    """BASELINE.json north_star: "Outputs match the reference path's flow_predictions[-1] on identical random
+    (1,448,512,3) inputs within 1e-3 max-abs EPE" -- FREE-RUNNING, all 24 iterations, asserted on every prediction
+    and in particular on [-1].  Weights: Keras-default except the contractive flow head of
+    tf_raft_amd.weights.condition_weights, for which the oracle agrees with itself (fp32 vs fp64) to < 2e-4 on every
+    iteration (tests/golden/conditioning.json); reference call site model.py:93-109, README.md:98-103."""
+    import oracle
+    import tf_raft_amd
+    cond = _assert_oracle_is_well_conditioned(f'{variant}_448x512_seed{seed}_it24_conditioned')
+    i1, i2, wts = _conditioned_case(variant, 448, 512, seed)
+    ocls, dcls = (oracle.RAFT, tf_raft_amd.RAFT) if variant == 'raft' else (oracle.SmallRAFT, tf_raft_amd.SmallRAFT)
+    want = ocls(wts, iters_pred=24)([i1, i2])
+    got = dcls(weights=wts, iters_pred=24)([i1, i2])
+    errs = [_max_epe(_np(g), w) for g, w in zip(got, want)]
+    report(f'north-star {variant} 448x512 seed {seed}', final_epe=errs[-1], worst_epe=max(errs),
+           oracle32_vs_64_final=cond['epe32v64'][-1], max_flow=float(np.abs(want[-1]).max()))
+    print('[parity] per-iteration max EPE hip-vs-oracle32 :', ' '.join(f'{e:.2e}' for e in errs))
+    assert len(got) == 24
+    assert errs[-1] <= TOL, errs[-1]
+    assert max(errs) <= TOL, errs
+    last = dcls(weights=wts, iters_pred=24).predict_step((i1, i2))       # the final-only loop gives the same [-1]
+    assert _max_epe(_np(last), want[-1]) <= TOL
+
+
+def test_north_star_benchmarked_batches():
+    """The benchmarked configurations: B=4 (BASELINE configs[1]) and B=8 (configs[2] per GPU) at 448x512, 24 iterations
+    free-running.  Kernel / tile selection depends on B, so each batch element is compared with the oracle run on that
+    element ALONE (B=1 on the CPU), at 1e-3 on flow_predictions[-1] and on every other prediction."""
+    import oracle
+    import tf_raft_amd
+    _assert_oracle_is_well_conditioned('raft_448x512_seed0_it24_conditioned')
+    i1, i2, wts = _conditioned_case('raft', 448, 512, 3, B=8)
+    want = [oracle.RAFT(wts, iters_pred=24)([i1[b:b + 1], i2[b:b + 1]]) for b in range(8)]
+    for B in (4, 8):
+        model = tf_raft_amd.RAFT(weights=wts, iters_pred=24)
+        got = model([i1[:B], i2[:B]])
+        worst = 0.0
+        for b in range(B):
+            errs = [_max_epe(_np(g)[b:b + 1], w) for g, w in zip(got, want[b])]
+            worst = max(worst, max(errs))
+            assert errs[-1] <= TOL, (B, b, errs[-1])
+            assert max(errs) <= TOL, (B, b, errs)
+        last = model.predict_step((i1[:B], i2[:B]))
+        np.testing.assert_array_equal(last.numpy(), got[-1].numpy())
+        report(f'north-star raft 448x512 B={B}', worst_epe_any_iteration_any_element=worst)
+
+
+def test_alternate_corr_1024_matches_oracle():
+    """BASELINE config 4: RAFT at (1,1024,1024,3) with alternate_corr=True (no stored volume) against the oracle's
+    stored-volume forward (1.07 GB volume on the CPU), 3 free-running iterations, conditioned weights."""
+    import oracle
+    import tf_raft_amd
+    _assert_oracle_is_well_conditioned('raft_1024x1024_seed0_it3_conditioned')
+    i1, i2, wts = _conditioned_case('raft', 1024, 1024, 0)
+    want = oracle.RAFT(wts, iters_pred=3)([i1, i2])
+    got = tf_raft_amd.RAFT(weights=wts, iters_pred=3, alternate_corr=True)([i1, i2])
+    errs = [_max_epe(_np(g), w) for g, w in zip(got, want)]
+    report('alternate corr 1024x1024 vs oracle', final_epe=errs[-1], worst_epe=max(errs))
+    assert max(errs) <= TOL, errs
+    vol = tf_raft_amd.RAFT(weights=wts, iters_pred=3)([i1, i2])           # the stored-volume HIP path at the same size
+    errs_v = [_max_epe(_np(g), w) for g, w in zip(vol, want)]
+    report('stored volume 1024x1024 vs oracle', final_epe=errs_v[-1], worst_epe=max(errs_v))
+    assert max(errs_v) <= TOL, errs_v
 
 
 # ------------------------------------------------------------------ full size (BASELINE shape), teacher-forced
@@ -284,7 +368,8 @@ def test_free_running_full_size_raft_reported():
     horizon = next((i for i, e in enumerate(errs) if e > TOL), 24)
     o_horizon = next((i for i, e in enumerate(cond['epe32v64']) if e > TOL), 24)
     print(f'[parity] first iteration above 1e-3: hip-vs-oracle32 {horizon}, oracle32-vs-oracle64 {o_horizon}')
-    assert horizon >= 2
+    # the HIP path must stay within tolerance as long as the oracle does against its own fp64 run (minus one iteration)
+    assert horizon >= o_horizon - 1, (horizon, o_horizon)
     assert errs[-1] <= 10 * max(cond['epe32v64'][-1], 0.5)
 
 
@@ -314,3 +399,35 @@ def test_three_stream_loop_is_bitwise_the_single_stream_loop():
         got = [_np(p) for p in model([i1, i2])]
         for a, b in zip(got, ref):
             assert np.array_equal(a, b)
+
+
+def test_graph_replayed_loop_is_bitwise_the_launched_loop(raft_opt):
+    """RAFT_LOOP_GRAPH (include/raft_hip.h): the three-stream loop captured into a hipGraph and replayed with one launch
+    must reproduce the host-launched loop bit for bit -- first call (capture + launch), repeated calls (cached graph),
+    another input of the same shape (same graph, new data), predict_step (its own graph), and the reference's canonical
+    single-pair shape class (B = 1)."""
+    import tf_raft_amd
+    from tf_raft_amd import weights as wm
+    wts = wm.init_weights('raft', seed=2)
+    model = tf_raft_amd.RAFT(weights=wts, iters_pred=6, overlap=True, name='raft_graph')
+    assert model.name == 'raft_graph'                       # reference model.py:11-12: **kwargs reach keras.Model(name=)
+    pairs = [_images(4, 1, 128, 192), _images(5, 1, 128, 192)]
+    raft_opt.set('RAFT_LOOP_GRAPH', '0')
+    ref = [[_np(p) for p in model([a, b])] for a, b in pairs]
+    ref_last = [_np(model.predict_step((a, b))) for a, b in pairs]
+    raft_opt.set('RAFT_LOOP_GRAPH', '1')
+    for _ in range(3):
+        for k, (a, b) in enumerate(pairs):
+            got = [_np(p) for p in model([a, b])]
+            for x, y in zip(got, ref[k]):
+                assert np.array_equal(x, y)
+            assert np.array_equal(_np(model.predict_step((a, b))), ref_last[k])
+    # a switch flipped between calls must not replay a stale graph (the key carries the option generation)
+    raft_opt.set('RAFT_GRU_WINO4', '0')
+    raft_opt.set('RAFT_GRU_WINO', '0')
+    direct = [_np(p) for p in model(list(pairs[0]))]
+    raft_opt.set('RAFT_LOOP_GRAPH', '0')
+    direct_ref = [_np(p) for p in model(list(pairs[0]))]
+    for x, y in zip(direct, direct_ref):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(direct[-1], ref[0][-1])       # the direct GRU kernels round differently from F(4,5)

@@ -273,9 +273,49 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in include/raft_hip.h but not exported'
     assert sorted(_ffi.EXPORTED_SYMBOLS) == names, 'ctypes signature table and header disagree'
     typed = _ffi.load_library()
-    assert typed.raft_version() == 101
+    assert typed.raft_version() == _ffi.ABI_VERSION
+    with open(os.path.join(ROOT, 'include', 'raft_hip.h')) as f:
+        assert int(re.search(r'#define RAFT_HIP_VERSION (\d+)', f.read()).group(1)) == _ffi.ABI_VERSION
     assert b'NULL' in typed.raft_error_string(-1)
     assert typed.raft_error_string(0) == b'ok'
+
+
+def test_tuning_switches_are_a_table_not_getenv():
+    """raft_set_option / raft_get_option (host-only): unknown names are rejected, values round-trip, NULL returns to
+    the load-time state; and no launch path calls getenv (only the one-time table initialiser in host_util.hip may)."""
+    assert _ffi.get_option('RAFT_GRU_WINO') == os.environ.get('RAFT_GRU_WINO', '')
+    _ffi.set_option('RAFT_GRU_WINO', 5)
+    assert _ffi.get_option('RAFT_GRU_WINO') == '5'
+    _ffi.set_option('RAFT_GRU_WINO', '')
+    assert _ffi.get_option('RAFT_GRU_WINO') == ''
+    _ffi.set_option('RAFT_GRU_WINO', None)
+    _ffi.set_option('RAFT_CONV_TILE', '256:5:171,128:5:141')
+    assert _ffi.get_option('RAFT_CONV_TILE') == '256:5:171,128:5:141'
+    _ffi.set_option('RAFT_CONV_TILE', None)
+    with pytest.raises(ValueError):
+        _ffi.set_option('RAFT_NO_SUCH_SWITCH', 1)
+    csrc = os.path.join(ROOT, 'tf_raft_amd', 'csrc')
+    for name in os.listdir(csrc):
+        if name == 'host_util.hip':
+            continue
+        with open(os.path.join(csrc, name)) as f:
+            assert 'getenv' not in re.sub(r'//.*', '', f.read()), f'{name} reads the environment on a launch path'
+
+
+@pytest.mark.parametrize('path', ['tf_raft.model', 'tf_raft.losses', 'tf_raft.losses.losses', 'tf_raft.layers.corr',
+                                  'tf_raft.layers.update', 'tf_raft.layers.extractor'])
+def test_every_reference_import_path_resolves(path):
+    """The reference's own import statements (train_sintel.py:8-9, tf_raft/model.py:4-6, tests/) work on the shim."""
+    import importlib
+    mod = importlib.import_module(path)
+    names = {'tf_raft.model': ['RAFT', 'SmallRAFT'],
+             'tf_raft.losses': ['sequence_loss', 'end_point_error', 'EndPointError'],
+             'tf_raft.losses.losses': ['sequence_loss', 'end_point_error', 'EndPointError'],
+             'tf_raft.layers.corr': ['CorrBlock', 'bilinear_sampler', 'coords_grid', 'upflow8'],
+             'tf_raft.layers.update': ['BasicUpdateBlock', 'SmallUpdateBlock'],
+             'tf_raft.layers.extractor': ['BasicEncoder', 'SmallEncoder']}[path]
+    for n in names:
+        assert hasattr(mod, n), (path, n)
 
 
 def _header_struct_fields(name):

@@ -310,8 +310,20 @@ def test_conditioning_fixture_matches_its_generator():
     spec.loader.exec_module(mk)
     with open(os.path.join(GOLDEN, 'conditioning.json')) as f:
         cond = json.load(f)
-    got = mk.run('small', 64, 96, 12, 0)
+    got = mk.run('small', 64, 96, 12, 0, 'default')
     want = cond['small_64x96_seed0_it12']
     assert len(got['epe32v64']) == 12
     assert max(got['epe32v64']) <= 1e-3 and max(want['epe32v64']) <= 1e-3
     np.testing.assert_allclose(got['max_abs_flow'], want['max_abs_flow'], rtol=1e-3)
+    # the conditioned regime (flow head of tf_raft_amd.weights.condition_weights): smallest committed case
+    got = mk.run('small', 256, 256, 4, 0, 'conditioned')
+    want = cond[mk.case_key('small', 256, 256, 4, 0, 'conditioned')]
+    np.testing.assert_allclose(got['max_abs_flow'], want['max_abs_flow'], rtol=1e-3)
+    assert max(got['epe32v64']) <= 1e-4
+    # every committed north-star case is well conditioned for all of its iterations, and its flow stays inside (0, 8) px
+    # at full resolution = (0, 1) feature pixels: no lookup tap can cross an integer
+    ns = [k for k in cond if k.endswith('_conditioned')]
+    assert len([k for k in ns if k.startswith('raft_448x512')]) >= 3 and len([k for k in ns if k.startswith('small_448x512')]) >= 3
+    for k in ns:
+        assert max(cond[k]['epe32v64']) <= 2e-4, k
+        assert max(cond[k]['max_abs_flow']) < 8.0, k

@@ -11,6 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
+ABI_VERSION = 200     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -56,6 +57,10 @@ _I = C.c_int
 _SIGNATURES = {
     'raft_version': (C.c_int, []),
     'raft_error_string': (C.c_char_p, [_I]),
+    'raft_set_option': (_I, [C.c_char_p, C.c_char_p]),
+    'raft_get_option': (_I, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    'raft_loop_ctx_create': (_I, [C.POINTER(C.c_void_p)]),
+    'raft_loop_ctx_destroy': (_I, [C.c_void_p]),
     'raft_crc32c': (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     'raft_corr_pyramid_layout': (_I, [_I, _I, _I, _I, c_i64_p, c_int_p, c_int_p]),
     'raft_corr_build_workspace_floats': (C.c_int64, [_I, _I, _I, _I, _I]),
@@ -83,11 +88,11 @@ _SIGNATURES = {
     'raft_iterate_basic_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
                                     C.POINTER(State), _P, _P]),
     'raft_iterate_basic_overlap_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
-                                            C.POINTER(State), _P, _P, _P, _P]),
+                                            C.POINTER(State), _P, _P, _P, _P, _P]),
     'raft_iterate_basic_ondemand_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, _P, _I, _I, _I, _I, _I,
-                                        C.POINTER(State), _P, _P, _P, _P]),
+                                        C.POINTER(State), _P, _P, _P, _P, _P]),
     'raft_iterate_basic_final_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
-                                          C.POINTER(State), _P, _P, _P, _P]),
+                                          C.POINTER(State), _P, _P, _P, _P, _P]),
     'raft_iterate_basic_timed_f32': (_I, [C.POINTER(BasicUpdateWeights), _P, c_i64_p, _I, _I, _I, _I,
                                           C.POINTER(State), _P, _P, C.POINTER(C.c_float)]),
     'raft_encoder_workspace_floats': (C.c_int64, [C.POINTER(EncoderWeights), _I, _I, _I]),
@@ -107,17 +112,19 @@ def library_path() -> str:
 
 
 def load_library():
-    """Load (building first if the .so is absent and hipcc is available) and type the library."""
+    """Load and type the library.  When hipcc is available the build is refreshed first (a digest of sources + flags
+    makes that a no-op for an up-to-date .so), so a stale library never meets newer struct mirrors; without hipcc the
+    prebuilt .so is used as is.  Either way ``raft_version()`` must equal ``ABI_VERSION``."""
     global _LIB
     with _LOCK:
         if _LIB is not None:
             return _LIB
         path = library_path()
-        if not os.path.exists(path):
-            from . import build as _build
-            try:
-                _build.build_library(verbose=False)
-            except Exception as exc:   # noqa: BLE001
+        from . import build as _build
+        try:
+            _build.build_library(verbose=False)
+        except Exception as exc:   # noqa: BLE001
+            if not os.path.exists(path):
                 raise RuntimeError(
                     f'libraft_hip.so is missing at {path} and could not be built ({exc}); '
                     'the RAFT device path has no CPU fallback') from exc
@@ -129,8 +136,23 @@ def load_library():
             fn = getattr(lib, name)          # AttributeError => symbol missing: fail loudly
             fn.restype = res
             fn.argtypes = args
+        if lib.raft_version() != ABI_VERSION:
+            raise RuntimeError(f'{path} reports ABI {lib.raft_version()}, this binding mirrors ABI {ABI_VERSION}: '
+                               'rebuild the library (python -m tf_raft_amd.build --force)')
         _LIB = lib
         return lib
+
+
+def set_option(name: str, value) -> None:
+    """``raft_set_option``: ``value`` None = load-time (environment) state, '' = built-in default."""
+    v = None if value is None else str(value).encode()
+    check(load_library().raft_set_option(name.encode(), v), f'set_option {name}')
+
+
+def get_option(name: str) -> str:
+    buf = C.create_string_buffer(256)
+    check(load_library().raft_get_option(name.encode(), buf, 256), f'get_option {name}')
+    return buf.value.decode()
 
 
 def check(rc: int, what: str = '') -> None:

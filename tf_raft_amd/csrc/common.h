@@ -44,6 +44,21 @@ __host__ __device__ inline int raft_tiled_index(int y, int x, int tiles_x) {
     return (((y >> 2) * tiles_x + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
 }
 
+// Tuning switches (include/raft_hip.h: raft_set_option).  Process-global, initialised ONCE from the environment when the
+// library is loaded and changed only through raft_set_option afterwards: the launch path reads an atomic int, it never
+// calls getenv.  raft_opt(id, dflt) = the switch's value, or dflt while it is unset.
+enum RaftOptionId {
+    RAFT_OPT_CONV_WINO, RAFT_OPT_SMALL_WINO, RAFT_OPT_GRU_WINO, RAFT_OPT_GRU_WINO4, RAFT_OPT_WINO_TNW, RAFT_OPT_WINO_SB,
+    RAFT_OPT_WINO_CK, RAFT_OPT_WINO1D_TM, RAFT_OPT_CONV_DEEP, RAFT_OPT_LOOKUP_LDS_PAD, RAFT_OPT_LOOKUP_STAGED,
+    RAFT_OPT_LOOKUP_KERNEL, RAFT_OPT_ONDEMAND_BLOCK, RAFT_OPT_ENC_TILE, RAFT_OPT_ENC_WINO, RAFT_OPT_LOOP_GRAPH,
+    RAFT_OPT_COUNT
+};
+int raft_opt(int id, int dflt);
+bool raft_opt_is_set(int id);
+int raft_opt_generation();   // bumped by every raft_set_option call
+// RAFT_CONV_TILE ("<code>" or "<npad>:<taps>:<code>,..."): the tile code forced for a convolution, or -1
+int raft_opt_conv_tile(int npad, int taps, bool (*valid)(int code, int npad));
+
 struct PyramidGeom {
     int64_t off[RAFT_MAX_LEVELS];   // float offset of each level of the corr pyramid
     int lh[RAFT_MAX_LEVELS];

@@ -60,23 +60,7 @@ static bool code_valid(int code, int npad) {
     }
     return false;
 }
-static int forced_code(int npad, int taps) {
-    const char *env = getenv("RAFT_CONV_TILE");
-    if (!env || !*env) return -1;
-    if (!strchr(env, ':')) {
-        const int t = atoi(env);
-        return code_valid(t, npad) ? t : -1;
-    }
-    const char *p = env;
-    while (*p) {
-        int n = 0, k = 0, t = 0;
-        if (sscanf(p, "%d:%d:%d", &n, &k, &t) == 3 && n == npad && k == taps && code_valid(t, npad)) return t;
-        p = strchr(p, ',');
-        if (!p) break;
-        ++p;
-    }
-    return -1;
-}
+static int forced_code(int npad, int taps) { return raft_opt_conv_tile(npad, taps, code_valid); }
 
 // Pick the halo tile (TH x 16 pixels, 64*TN channels) by a small cost model of MI355X (256 CUs):
 //   time ~ (workgroups per CU, rounded up) x (MFMA work of one tile) x (latency-hiding penalty),
@@ -228,10 +212,8 @@ constexpr int RAFT_GRU_WINO_DEFAULT = 15;
 constexpr int RAFT_GRU_WINO4_DEFAULT = 15;
 static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weights &wino, const raft_conv_weights &wino4,
                            int bit, ConvArgs a, int kh, int kw, int epi, hipStream_t s) {
-    const char *e = getenv("RAFT_GRU_WINO");
-    const int mask = e ? atoi(e) : RAFT_GRU_WINO_DEFAULT;
-    const char *e4 = getenv("RAFT_GRU_WINO4");
-    const int mask4 = e4 ? atoi(e4) : RAFT_GRU_WINO4_DEFAULT;
+    const int mask = raft_opt(RAFT_OPT_GRU_WINO, RAFT_GRU_WINO_DEFAULT);
+    const int mask4 = raft_opt(RAFT_OPT_GRU_WINO4, RAFT_GRU_WINO4_DEFAULT);
     if ((mask4 & bit) && wino4.wp != nullptr && a.c0 % 32 == 0 && a.c1 % 32 == 0) {
         a.wp = wino4.wp;
         a.bias = wino4.bias;
@@ -258,8 +240,7 @@ constexpr int RAFT_WINO_DEFAULT = 13;
 constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr, 4: gru_q, 8: fh1}, switch RAFT_SMALL_WINO
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
                           hipStream_t s, bool small = false) {
-    const char *e = getenv(small ? "RAFT_SMALL_WINO" : "RAFT_CONV_WINO");
-    const int mask = e ? atoi(e) : (small ? RAFT_SMALL_WINO_DEFAULT : RAFT_WINO_DEFAULT);
+    const int mask = small ? raft_opt(RAFT_OPT_SMALL_WINO, RAFT_SMALL_WINO_DEFAULT) : raft_opt(RAFT_OPT_CONV_WINO, RAFT_WINO_DEFAULT);
     if ((mask & bit) && wino.wp != nullptr) {
         a.wp = wino.wp;
         a.bias = wino.bias;
@@ -699,20 +680,69 @@ static int loop_lookup(const LookupSource &src, const raft_state *st, int B, int
     return raft_corr_lookup_ondemand_f32(src.fmap1, src.fmap2_pyr, st->coords1, B, h, w, src.C, 4, 4, st->corr, CORR_LD, stream);
 }
 
+// Caller-owned loop context (include/raft_hip.h): the four cross-stream events of the three-stream schedule, created
+// ONCE by raft_loop_ctx_create (the only allocating entry point), plus a small cache of instantiated hipGraphs of whole
+// prediction loops keyed by every argument of the call.
+struct LoopKey {
+    raft_basic_update_weights wts;
+    LookupSource src;
+    raft_state st;
+    int64_t offs[RAFT_MAX_LEVELS + 1];   // VALUES of level_offsets (the pointer is host memory of the caller)
+    const float *flow_up;
+    void *stream, *aux0, *aux1;
+    int B, h, w, iters, final_only, opt_stamp;
+};
+struct LoopGraph {
+    LoopKey key;
+    hipGraphExec_t exec;
+    uint64_t last_use;
+};
+struct raft_loop_ctx {
+    hipEvent_t ev[4];
+    LoopGraph graphs[4];
+    int n_graphs;
+    uint64_t clock;
+    int device;
+};
+
 static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, const LookupSource &src, int B, int h, int w,
                                       int iters, const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1,
-                                      bool final_only = false);
+                                      raft_loop_ctx *ctx, bool final_only = false);
+
+extern "C" int raft_loop_ctx_create(raft_loop_ctx **out) {
+    RAFT_REQUIRE_PTR(out);
+    raft_loop_ctx *c = (raft_loop_ctx *)calloc(1, sizeof(raft_loop_ctx));
+    if (!c) return (int)hipErrorOutOfMemory;
+    int rc = (int)hipGetDevice(&c->device);
+    int made = 0;
+    for (; made < 4 && rc == RAFT_OK; ++made) rc = (int)hipEventCreateWithFlags(&c->ev[made], hipEventDisableTiming);
+    if (rc != RAFT_OK) {
+        for (int k = 0; k < made - 1; ++k) (void)hipEventDestroy(c->ev[k]);
+        free(c);
+        return rc;
+    }
+    *out = c;
+    return RAFT_OK;
+}
+
+extern "C" int raft_loop_ctx_destroy(raft_loop_ctx *c) {
+    if (!c) return RAFT_OK;
+    for (int k = 0; k < c->n_graphs; ++k) (void)hipGraphExecDestroy(c->graphs[k].exec);
+    for (int k = 0; k < 4; ++k) (void)hipEventDestroy(c->ev[k]);
+    free(c);
+    return RAFT_OK;
+}
 
 // raft_iterate_basic_f32 on three streams (see struct Overlap).  aux0 / aux1 are caller-owned streams
 // distinct from `stream`; all work is joined back into `stream` before returning.
 extern "C" int raft_iterate_basic_overlap_f32(const raft_basic_update_weights *wts, const float *pyr,
                                               const int64_t *level_offsets, int B, int h, int w, int iters,
                                               const raft_state *st, float *flow_up, void *stream, void *aux0,
-                                              void *aux1) {
+                                              void *aux1, raft_loop_ctx *ctx) {
     RAFT_REQUIRE_PTR(pyr);
     RAFT_REQUIRE_PTR(level_offsets);
     const LookupSource src = {pyr, level_offsets, nullptr, nullptr, 0};
-    return iterate_basic_overlap_impl(wts, src, B, h, w, iters, st, flow_up, stream, aux0, aux1);
+    return iterate_basic_overlap_impl(wts, src, B, h, w, iters, st, flow_up, stream, aux0, aux1, ctx);
 }
 
 // The same three-stream loop with the volume-free ("alternate") correlation: every iteration's lookup computes its
@@ -720,11 +750,11 @@ extern "C" int raft_iterate_basic_overlap_f32(const raft_basic_update_weights *w
 extern "C" int raft_iterate_basic_ondemand_f32(const raft_basic_update_weights *wts, const float *fmap1,
                                                const float *fmap2_pyr, int C, int B, int h, int w, int iters,
                                                const raft_state *st, float *flow_up, void *stream, void *aux0,
-                                               void *aux1) {
+                                               void *aux1, raft_loop_ctx *ctx) {
     RAFT_REQUIRE_PTR(fmap1);
     RAFT_REQUIRE_PTR(fmap2_pyr);
     const LookupSource src = {nullptr, nullptr, fmap1, fmap2_pyr, C};
-    return iterate_basic_overlap_impl(wts, src, B, h, w, iters, st, flow_up, stream, aux0, aux1);
+    return iterate_basic_overlap_impl(wts, src, B, h, w, iters, st, flow_up, stream, aux0, aux1, ctx);
 }
 
 // The prediction loop for callers that only want flow_predictions[-1] (reference model.py:160-166, predict_step): the
@@ -734,36 +764,29 @@ extern "C" int raft_iterate_basic_ondemand_f32(const raft_basic_update_weights *
 extern "C" int raft_iterate_basic_final_f32(const raft_basic_update_weights *wts, const float *pyr,
                                             const int64_t *level_offsets, int B, int h, int w, int iters,
                                             const raft_state *st, float *flow_up_last, void *stream, void *aux0,
-                                            void *aux1) {
+                                            void *aux1, raft_loop_ctx *ctx) {
     RAFT_REQUIRE_PTR(wts);
     RAFT_REQUIRE_PTR(pyr);
     RAFT_REQUIRE_PTR(level_offsets);
     RAFT_REQUIRE(wts->fh1_w.wp != nullptr, RAFT_E_NULL);
     const LookupSource src = {pyr, level_offsets, nullptr, nullptr, 0};
-    return iterate_basic_overlap_impl(wts, src, B, h, w, iters, st, flow_up_last, stream, aux0, aux1, true);
+    return iterate_basic_overlap_impl(wts, src, B, h, w, iters, st, flow_up_last, stream, aux0, aux1, ctx, true);
 }
 
-static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, const LookupSource &src, int B, int h, int w,
-                                      int iters, const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1,
-                                      bool final_only) {
-    RAFT_REQUIRE_PTR(wts);
-    RAFT_REQUIRE_PTR(flow_up);
-    RAFT_REQUIRE_PTR(aux0);
-    RAFT_REQUIRE_PTR(aux1);
-    RAFT_TRY(check_state(st));
-    RAFT_REQUIRE(B > 0 && h > 0 && w > 0 && iters > 0, RAFT_E_SHAPE);
-    RAFT_REQUIRE(aux0 != stream && aux1 != stream && aux0 != aux1, RAFT_E_UNSUPPORTED);
+// Enqueue the whole loop on `stream` + the two side streams (also the body of a stream capture).
+static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource &src, int B, int h, int w, int iters,
+                        const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1, raft_loop_ctx *ctx,
+                        bool final_only) {
     hipStream_t s = (hipStream_t)stream;
     Overlap ov = {};
     ov.s1 = (hipStream_t)aux0;
     ov.s2 = (hipStream_t)aux1;
-    hipEvent_t *evs[4] = {&ov.e_fh, &ov.e_f, &ov.e_fm, &ov.e_up};
-    int rc = RAFT_OK;
-    int made = 0;
-    for (; made < 4 && rc == RAFT_OK; ++made) rc = (int)hipEventCreateWithFlags(evs[made], hipEventDisableTiming);
-    if (rc != RAFT_OK) --made;
+    ov.e_fh = ctx->ev[0];
+    ov.e_f = ctx->ev[1];
+    ov.e_fm = ctx->ev[2];
+    ov.e_up = ctx->ev[3];
     const int64_t up = (int64_t)B * 64 * h * w * 2;
-    if (rc == RAFT_OK) rc = (int)hipEventRecord(ov.e_fh, s);   // state prepared on `stream`: the flow branch may start
+    int rc = (int)hipEventRecord(ov.e_fh, s);   // state prepared on `stream`: the flow branch may start
     for (int i = 0; i < iters && rc == RAFT_OK; ++i) {
         const bool with_mask = !final_only || i == iters - 1;
         rc = loop_lookup(src, st, B, h, w, stream);
@@ -776,12 +799,99 @@ static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, cons
         ov.have_up = true;
     }
     if (rc == RAFT_OK && ov.have_up) rc = (int)hipStreamWaitEvent(s, ov.e_up, 0);   // join
-    if (rc != RAFT_OK) {   // never leave side streams running behind an error return
-        (void)hipStreamSynchronize(ov.s1);
-        (void)hipStreamSynchronize(ov.s2);
-    }
-    for (int k = 0; k < made; ++k) (void)hipEventDestroy(*evs[k]);
     return rc;
+}
+
+// Padding-free copy of the weight table (it is an array of raft_conv_weights): the key is compared with memcmp.
+static void copy_weights_clean(raft_basic_update_weights *dst, const raft_basic_update_weights *src) {
+    static_assert(sizeof(raft_basic_update_weights) % sizeof(raft_conv_weights) == 0, "weight table = array of raft_conv_weights");
+    memset(dst, 0, sizeof(*dst));
+    const raft_conv_weights *sw = (const raft_conv_weights *)src;
+    raft_conv_weights *dw = (raft_conv_weights *)dst;
+    for (size_t i = 0; i < sizeof(*src) / sizeof(raft_conv_weights); ++i) {
+        dw[i].wp = sw[i].wp;
+        dw[i].bias = sw[i].bias;
+        dw[i].npad = sw[i].npad;
+    }
+}
+
+// RAFT_LOOP_GRAPH (raft_set_option): 1 = replay the loop as ONE hipGraph launch (captured from the same enqueue code the
+// first time a given set of arguments is seen, then cached in the caller's raft_loop_ctx), 0 = enqueue ~350 kernels and
+// ~100 event operations from the host every call.  Default: graphs for small batches (B * h * w <= 2 * 3584 pixels: the
+// kernels there are shorter than the host's per-launch cost), plain launches above -- DESIGN.md section 4.2.
+static bool use_loop_graph(int B, int h, int w) {
+    const int dflt = (int64_t)B * h * w <= 2 * 3584 ? 1 : 0;
+    return raft_opt(RAFT_OPT_LOOP_GRAPH, dflt) != 0;
+}
+
+static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, const LookupSource &src, int B, int h, int w,
+                                      int iters, const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1,
+                                      raft_loop_ctx *ctx, bool final_only) {
+    RAFT_REQUIRE_PTR(wts);
+    RAFT_REQUIRE_PTR(flow_up);
+    RAFT_REQUIRE_PTR(aux0);
+    RAFT_REQUIRE_PTR(aux1);
+    RAFT_REQUIRE_PTR(ctx);
+    RAFT_TRY(check_state(st));
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0 && iters > 0, RAFT_E_SHAPE);
+    RAFT_REQUIRE(aux0 != stream && aux1 != stream && aux0 != aux1, RAFT_E_UNSUPPORTED);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (!use_loop_graph(B, h, w) || s == nullptr) {   // the legacy NULL stream cannot be captured
+        rc = enqueue_loop(wts, src, B, h, w, iters, st, flow_up, stream, aux0, aux1, ctx, final_only);
+        if (rc != RAFT_OK) {   // never leave side streams running behind an error return
+            (void)hipStreamSynchronize((hipStream_t)aux0);
+            (void)hipStreamSynchronize((hipStream_t)aux1);
+        }
+        return rc;
+    }
+    LoopKey key;
+    memset(&key, 0, sizeof(key));   // padding bytes take part in the memcmp below
+    copy_weights_clean(&key.wts, wts);
+    key.src.pyr = src.pyr;
+    key.src.fmap1 = src.fmap1;
+    key.src.fmap2_pyr = src.fmap2_pyr;
+    key.src.C = src.C;
+    if (src.level_offsets)
+        for (int l = 0; l <= RAFT_MAX_LEVELS; ++l) key.offs[l] = src.level_offsets[l];
+    key.st = *st;   // nine pointers, no padding
+    key.flow_up = flow_up;
+    key.stream = stream;
+    key.aux0 = aux0;
+    key.aux1 = aux1;
+    key.B = B; key.h = h; key.w = w; key.iters = iters;
+    key.final_only = final_only ? 1 : 0;
+    key.opt_stamp = raft_opt_generation();   // any raft_set_option call may change which kernels the loop launches
+    ++ctx->clock;
+    for (int k = 0; k < ctx->n_graphs; ++k)
+        if (memcmp(&ctx->graphs[k].key, &key, sizeof(key)) == 0) {
+            ctx->graphs[k].last_use = ctx->clock;
+            return (int)hipGraphLaunch(ctx->graphs[k].exec, s);
+        }
+    // capture the enqueue code: the event record / wait pairs pull the two side streams into the capture
+    rc = (int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (rc != RAFT_OK) return rc;
+    rc = enqueue_loop(wts, src, B, h, w, iters, st, flow_up, stream, aux0, aux1, ctx, final_only);
+    hipGraph_t graph = nullptr;
+    const int rc_end = (int)hipStreamEndCapture(s, &graph);
+    if (rc == RAFT_OK) rc = rc_end;
+    hipGraphExec_t exec = nullptr;
+    if (rc == RAFT_OK) rc = (int)hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc != RAFT_OK) return rc;
+    int slot = ctx->n_graphs;
+    if (slot == 4) {   // evict the least recently used graph
+        slot = 0;
+        for (int k = 1; k < 4; ++k)
+            if (ctx->graphs[k].last_use < ctx->graphs[slot].last_use) slot = k;
+        (void)hipGraphExecDestroy(ctx->graphs[slot].exec);
+    } else {
+        ++ctx->n_graphs;
+    }
+    ctx->graphs[slot].key = key;
+    ctx->graphs[slot].exec = exec;
+    ctx->graphs[slot].last_use = ctx->clock;
+    return (int)hipGraphLaunch(exec, s);
 }
 
 // Profiling twin of raft_iterate_basic_f32: identical launches, plus a HIP event after every kernel

@@ -400,8 +400,7 @@ int raft_launch_conv_halo_5x1(const ConvArgs &a, int th, int tn, int epi, hipStr
 // Deep weight prefetch (DEEP = 1) for the single-column-block tiles: measured +2..4 % on every update-block layer at
 // B = 4 (profiles/r03j_conv_bench_deep*.txt), same register occupancy.  RAFT_CONV_DEEP = 0 switches it off (A/B timing).
 static inline bool raft_conv_deep(const ConvArgs &, int, int tn, int) {
-    static const int mode = [] { const char *e = getenv("RAFT_CONV_DEEP"); return e ? atoi(e) : 1; }();
-    return tn == 1 && mode != 0;
+    return tn == 1 && raft_opt(RAFT_OPT_CONV_DEEP, 1) != 0;
 }
 
 template <int KH, int KW, int EPI>

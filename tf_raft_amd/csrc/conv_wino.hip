@@ -39,18 +39,15 @@ int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s) {
     }
     // channel blocks of 64 per workgroup when that still leaves >= 2 workgroups per CU, else blocks of 32
     const int tiles = a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32);
-    const char *e = getenv("RAFT_WINO_TNW");   // tuning / test override, read per call
-    const int forced = e ? atoi(e) : 0;
+    const int forced = raft_opt(RAFT_OPT_WINO_TNW, 0);   // tuning / test override (raft_set_option)
     int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) >= 512) ? 2 : 1;
     if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
     const int grid = tiles * (a.npad / (32 * tnw));
     // pinned weight prefetch (SB): always at TNW = 2; at TNW = 1 only when two workgroups per CU hold the whole grid
-    const char *sbe = getenv("RAFT_WINO_SB");   // tuning override: 0 / 1
-    const bool sb = sbe ? atoi(sbe) != 0 : (tnw == 2 || grid <= 512);
+    const bool sb = raft_opt(RAFT_OPT_WINO_SB, (tnw == 2 || grid <= 512) ? 1 : 0) != 0;   // tuning override: 0 / 1
     // 32 channels per barrier at TNW = 1 when the channel counts allow it (RAFT_WINO_CK = 1 / 2 overrides)
-    const char *cke = getenv("RAFT_WINO_CK");
     const bool ck2_ok = a.c0 % 32 == 0 && a.c1 % 32 == 0;
-    const bool ck2 = ck2_ok && (cke ? atoi(cke) == 2 : grid <= 512);   // 58 KB of LDS: two workgroups per CU
+    const bool ck2 = ck2_ok && raft_opt(RAFT_OPT_WINO_CK, grid <= 512 ? 2 : 1) == 2;   // 58 KB of LDS: two workgroups per CU
     if (tnw == 2) return sb ? launch_wino<2, 1, 1>(a, epi, grid, s) : launch_wino<2, 0, 1>(a, epi, grid, s);
     if (ck2) return sb ? launch_wino<1, 1, 2>(a, epi, grid, s) : launch_wino<1, 0, 2>(a, epi, grid, s);
     return sb ? launch_wino<1, 1, 1>(a, epi, grid, s) : launch_wino<1, 0, 1>(a, epi, grid, s);

@@ -38,11 +38,9 @@ int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStrea
         if ((int64_t)(mo + 4) * (a.c0 + a.c1) * a.npad * 4 >= lim) return RAFT_E_UNSUPPORTED;
     }
     const int axis = kh == 5 ? 1 : 0;
-    const char *e = getenv("RAFT_WINO_TNW");   // tuning / test overrides, read per call
-    const int forced = e ? atoi(e) : 0;
-    const char *tme = getenv("RAFT_WINO1D_TM");
-    const char *cke = getenv("RAFT_WINO_CK");
-    const bool ck2 = a.c0 % 32 == 0 && a.c1 % 32 == 0 && (cke ? atoi(cke) == 2 : RAFT_WINO1D_CK2_DEFAULT);
+    const int forced = raft_opt(RAFT_OPT_WINO_TNW, 0);   // tuning / test overrides (raft_set_option)
+    const int tm_forced = raft_opt(RAFT_OPT_WINO1D_TM, 0);
+    const bool ck2 = a.c0 % 32 == 0 && a.c1 % 32 == 0 && raft_opt(RAFT_OPT_WINO_CK, RAFT_WINO1D_CK2_DEFAULT ? 2 : 1) == 2;
     auto tiles_of = [&](int tm) {
         return axis == 0 ? a.B * ((a.H + 2 * tm - 1) / (2 * tm)) * ((a.W + 31) / 32)
                          : a.B * ((a.H + 4 * tm - 1) / (4 * tm)) * ((a.W + 15) / 16);
@@ -63,7 +61,7 @@ int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStrea
     int tnw = a.npad % 64 == 0 ? 2 : 1;
     if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
     int tm = (int64_t)tiles_of(2) * (a.npad / (32 * tnw)) >= 400 ? 2 : 1;
-    if (tme && (atoi(tme) == 1 || atoi(tme) == 2)) tm = atoi(tme);
+    if (tm_forced == 1 || tm_forced == 2) tm = tm_forced;
     const int grid = tiles_of(tm) * (a.npad / (32 * tnw));
     if (axis == 0) return tm == 2 ? launch_wino1d_tm<0, 2>(a, epi, grid, tnw, ck2, s) : launch_wino1d_tm<0, 1>(a, epi, grid, tnw, ck2, s);
     return tm == 2 ? launch_wino1d_tm<1, 2>(a, epi, grid, tnw, ck2, s) : launch_wino1d_tm<1, 1>(a, epi, grid, tnw, ck2, s);

@@ -481,8 +481,7 @@ __global__ void __launch_bounds__(256) corr_lookup_strip_kernel(LookupArgs p) {
 template <int R>
 static void launch_lookup(const LookupArgs &a, bool staged, hipStream_t s) {
     const int grid = raft_ceil_div(a.nq, StripCfg<R>::QB);
-    const char *e = getenv("RAFT_LOOKUP_LDS_PAD");   // tuning switch: unused dynamic LDS caps the workgroups per CU
-    const int pad = e ? atoi(e) : 0;
+    const int pad = raft_opt(RAFT_OPT_LOOKUP_LDS_PAD, 0);   // tuning switch: unused dynamic LDS caps the workgroups per CU
     if (staged)
         corr_lookup_strip_kernel<R, 1><<<grid, 256, pad, s>>>(a);
     else
@@ -507,8 +506,8 @@ extern "C" int raft_corr_lookup_f32(const float *pyr, const int64_t *level_offse
     a.nq = (int64_t)B * h * w;
     a.ld_out = ld_out;
     hipStream_t s = (hipStream_t)stream;
-    const char *ver = getenv("RAFT_LOOKUP_STAGED");   // A/B timing switch only: 0 = direct strip stores
-    const bool staged = (ver ? atoi(ver) != 0 : true) && levels == 4 && (ld_out & 3) == 0 && raft_aligned16(out);
+    // A/B timing switch only: 0 = direct strip stores
+    const bool staged = raft_opt(RAFT_OPT_LOOKUP_STAGED, 1) != 0 && levels == 4 && (ld_out & 3) == 0 && raft_aligned16(out);
     if (radius == 4)
         launch_lookup<4>(a, staged, s);
     else if (radius == 3)

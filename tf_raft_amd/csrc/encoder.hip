@@ -162,9 +162,8 @@ int enc_conv(const ConvArgs &a, EncKind kind, int epi, int th, int tn, hipStream
 void enc_pick(int H, int npad, int *th, int *tn) {
     *th = (H % 7 == 0) ? 7 : 8;
     *tn = 1;
-    const char *env = getenv("RAFT_ENC_TILE");   // tuning override "<th><tn>", e.g. 72
-    if (env && *env) {
-        const int v = atoi(env), t = v / 10, n = v % 10;
+    if (raft_opt_is_set(RAFT_OPT_ENC_TILE)) {   // tuning override "<th><tn>", e.g. 72 (raft_set_option)
+        const int v = raft_opt(RAFT_OPT_ENC_TILE, 0), t = v / 10, n = v % 10;
         if ((t == 7 || t == 8) && (n == 1 || n == 2) && npad % (64 * n) == 0) {
             *th = t;
             *tn = n;
@@ -228,8 +227,7 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
         const int64_t tiles_w = (int64_t)n * 2 * ((h1 + 3) / 4) * ((w1 + 31) / 32);
         if (tiles_w > tiles_max) tiles_max = tiles_w;
     }
-    const char *wino_env = getenv("RAFT_ENC_WINO");   // 0: direct 3x3 kernels everywhere (A/B timing, parity tests)
-    const bool use_wino = wino_env ? atoi(wino_env) != 0 : true;
+    const bool use_wino = raft_opt(RAFT_OPT_ENC_WINO, 1) != 0;   // 0: direct 3x3 kernels everywhere (A/B timing, parity tests)
     EncBufs b;
     float *p = workspace;
     b.img4 = p; p += align4((int64_t)n * H * W * 4);

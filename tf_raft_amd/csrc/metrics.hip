@@ -94,11 +94,13 @@ __global__ void __launch_bounds__(256) sequence_loss_partial_kernel(const float2
     double acc[1] = {0.0};
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
         const float2 g = gt[i];
-        if (!pixel_valid(g, valid[i], max_flow)) continue;
+        // losses.py:14-19 MULTIPLIES by the 0/1 mask (it does not select): a NaN / Inf prediction or ground truth at a
+        // masked pixel makes the reference loss NaN (0 * NaN), and so it does here
+        const float m = pixel_valid(g, valid[i], max_flow) ? 1.0f : 0.0f;
         double s = 0.0;
         for (int k = 0; k < n_pred; ++k) {
             const float2 p = preds[(int64_t)k * pred_stride + i];
-            s += (double)lw.w[k] * ((double)fabsf(p.x - g.x) + (double)fabsf(p.y - g.y));   // losses.py:18-19
+            s += (double)lw.w[k] * ((double)(m * fabsf(p.x - g.x)) + (double)(m * fabsf(p.y - g.y)));   // losses.py:18-19
         }
         acc[0] += s;
     }

@@ -298,8 +298,7 @@ extern "C" int raft_corr_lookup_ondemand_f32(const float *fmap1, const float *fm
     const int blocks = raft_ceil_div(a.nq, 4);
     hipStream_t s = (hipStream_t)stream;
     {   // blocked MFMA kernel (RAFT_ONDEMAND_BLOCK=0 selects the wave-per-query kernel below: A/B timing, parity tests)
-        const char *e = getenv("RAFT_ONDEMAND_BLOCK");
-        const bool block = e ? atoi(e) != 0 : true;
+        const bool block = raft_opt(RAFT_OPT_ONDEMAND_BLOCK, 1) != 0;
         const int nblk = B * ((h + 3) / 4) * ((w + 3) / 4);
         if (block && radius == 4 && C == 256) {
             corr_lookup_ondemand_block_kernel<4, 256><<<nblk, 256, 0, s>>>(a, B, h, w);

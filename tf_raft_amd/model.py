@@ -21,6 +21,7 @@ provided.  ``train_step`` (backward pass + optimizer) is out of scope and raises
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from collections import OrderedDict
@@ -44,6 +45,9 @@ class RAFT:
 
     def __init__(self, drop_rate=0, iters=12, iters_pred=24, weights: Optional[Dict[str, np.ndarray]] = None,
                  seed=0, alternate_corr=False, overlap=None, **kwargs):
+        # reference model.py:11-12 forwards **kwargs to tf.keras.Model, whose constructor takes `name` (and nothing a
+        # forward pass depends on): accept it, reject the rest
+        self.name = kwargs.pop('name', type(self).__name__.lower())
         if kwargs:
             raise TypeError(f'unexpected keyword arguments {sorted(kwargs)}')
         self.hidden_dim = 128
@@ -59,6 +63,8 @@ class RAFT:
         self._aux = None
         self._enc_stream = None
         self._state = None
+        self._loop_ctx = None
+        self._loop_stream = None
         _dev.require_gpu()
         _dev.lib()
         if weights is None:
@@ -141,16 +147,55 @@ class RAFT:
             self._aux = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         return self._aux
 
+    @contextlib.contextmanager
+    def _capturable_stream(self, dev):
+        """The three-stream loops replay a captured hipGraph for small batches (include/raft_hip.h, RAFT_LOOP_GRAPH); the
+        legacy default stream (handle 0, torch's default) cannot be captured, so when the caller is on it the loop is
+        enqueued on a private stream ordered after / before the current one."""
+        cur = torch.cuda.current_stream(dev)
+        if cur.cuda_stream != 0:
+            yield
+            return
+        if self._loop_stream is None or self._loop_stream.device != dev:
+            self._loop_stream = torch.cuda.Stream(device=dev)
+        self._loop_stream.wait_stream(cur)
+        with torch.cuda.stream(self._loop_stream):
+            yield
+        cur.wait_stream(self._loop_stream)   # joined: buffers allocated on `cur` are safe to reuse after this point
+
+    def _loop_context(self, dev):
+        """The caller-owned ``raft_loop_ctx`` (cross-stream events + hipGraph cache) of the three-stream loops."""
+        if self._loop_ctx is None or self._loop_ctx[1] != dev:
+            self._free_loop_context()
+            handle = C.c_void_p()
+            with torch.cuda.device(dev):
+                check(_dev.lib().raft_loop_ctx_create(C.byref(handle)), 'loop_ctx_create')
+            self._loop_ctx = (handle, dev)
+        return self._loop_ctx[0]
+
+    def _free_loop_context(self):
+        if getattr(self, '_loop_ctx', None) is not None:
+            try:
+                torch.cuda.synchronize(self._loop_ctx[1])
+                _dev.lib().raft_loop_ctx_destroy(self._loop_ctx[0])
+            except Exception:   # noqa: BLE001  (interpreter shutdown)
+                pass
+            self._loop_ctx = None
+
+    def __del__(self):
+        self._free_loop_context()
+
     def _iterate(self, corr: CorrBlock, st, iters, flow_up):
         if self.overlap:
             # flow branch and mask branch of every iteration on two side streams (events inside the library)
             dev = flow_up.device
             if self._aux is None or self._aux[0].device != dev:
                 self._aux = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-            check(_dev.lib().raft_iterate_basic_overlap_f32(
-                C.byref(self.update_block.c), _dev.ptr(corr._pyr), corr._off, st.B, st.h, st.w, iters, C.byref(st.c),
-                _dev.ptr(flow_up), _dev.stream_ptr(), self._aux[0].cuda_stream, self._aux[1].cuda_stream),
-                'iterate_basic_overlap')
+            with self._capturable_stream(dev):
+                check(_dev.lib().raft_iterate_basic_overlap_f32(
+                    C.byref(self.update_block.c), _dev.ptr(corr._pyr), corr._off, st.B, st.h, st.w, iters, C.byref(st.c),
+                    _dev.ptr(flow_up), _dev.stream_ptr(), self._aux[0].cuda_stream, self._aux[1].cuda_stream,
+                    self._loop_context(dev)), 'iterate_basic_overlap')
             return
         check(_dev.lib().raft_iterate_basic_f32(C.byref(self.update_block.c), _dev.ptr(corr._pyr), corr._off,
                                                 st.B, st.h, st.w, iters, C.byref(st.c), _dev.ptr(flow_up),
@@ -162,10 +207,11 @@ class RAFT:
             dev = flow_up.device
             if self._aux is None or self._aux[0].device != dev:
                 self._aux = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-            check(_dev.lib().raft_iterate_basic_ondemand_f32(
-                C.byref(self.update_block.c), _dev.ptr(corr.fmap1), _dev.ptr(corr._f2pyr), corr.fmap1.shape[-1],
-                st.B, st.h, st.w, iters, C.byref(st.c), _dev.ptr(flow_up), _dev.stream_ptr(),
-                self._aux[0].cuda_stream, self._aux[1].cuda_stream), 'iterate_basic_ondemand')
+            with self._capturable_stream(dev):
+                check(_dev.lib().raft_iterate_basic_ondemand_f32(
+                    C.byref(self.update_block.c), _dev.ptr(corr.fmap1), _dev.ptr(corr._f2pyr), corr.fmap1.shape[-1],
+                    st.B, st.h, st.w, iters, C.byref(st.c), _dev.ptr(flow_up), _dev.stream_ptr(),
+                    self._aux[0].cuda_stream, self._aux[1].cuda_stream, self._loop_context(dev)), 'iterate_basic_ondemand')
             return
         g = st.g
         for i in range(iters):
@@ -218,10 +264,11 @@ class RAFT:
         iters = self.iters if training else self.iters_pred
         if final_only:
             last = torch.empty((B, H, W, 2), device=image1.device, dtype=torch.float32)
-            check(_dev.lib().raft_iterate_basic_final_f32(
-                C.byref(self.update_block.c), _dev.ptr(correlation._pyr), correlation._off, B, h, w, iters, C.byref(st.c),
-                _dev.ptr(last), _dev.stream_ptr(), self._aux_streams(last.device)[0].cuda_stream,
-                self._aux_streams(last.device)[1].cuda_stream), 'iterate_basic_final')
+            with self._capturable_stream(last.device):
+                check(_dev.lib().raft_iterate_basic_final_f32(
+                    C.byref(self.update_block.c), _dev.ptr(correlation._pyr), correlation._off, B, h, w, iters, C.byref(st.c),
+                    _dev.ptr(last), _dev.stream_ptr(), self._aux_streams(last.device)[0].cuda_stream,
+                    self._aux_streams(last.device)[1].cuda_stream, self._loop_context(last.device)), 'iterate_basic_final')
             self._last_correlation = correlation
             return _dev.wrap(last)
         flow_up = torch.empty((iters, B, H, W, 2), device=image1.device, dtype=torch.float32)

@@ -59,6 +59,9 @@ def predict_sharded(predict: Callable[[Sequence], List[torch.Tensor]], image1, i
     iterations when ``gather_all_iterations`` is set.
     """
     total = image1.shape[0]
+    if total == 0:
+        raise ValueError('predict_sharded needs at least one image pair in the global batch (individual ranks may still '
+                         'receive an empty shard when the batch is smaller than the world size)')
     if dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:

@@ -170,6 +170,26 @@ def init_weights(variant: str, seed: int = 0, perturb: bool = False) -> 'Ordered
     return w
 
 
+# Contractive flow-head regime for free-running parity tests (tests/golden/make_conditioning.py).
+# With Keras-default weights an untrained RAFT's flow grows ~7 px per iteration, taps cross the sampler's clamp
+# discontinuity (reference corr.py:41-48: a clamped coordinate is an integer and samples 0) and ANY two fp32
+# evaluations of the recurrence -- the oracle in fp32 and in fp64 included -- part ways after ~10 iterations.
+# Scaling flow_head.conv2 and giving it a small positive bias keeps every coordinate x + flow strictly inside
+# (x, x + 1) for the whole loop (flow in ~[0.1, 0.9] px after 24 iterations), so no tap can flip and the 1e-3 bound of
+# BASELINE.json's north_star is testable on flow_predictions[-1] itself.  Every other layer keeps its default weights.
+CONDITIONED_HEAD = {'raft': (0.01, (0.02, 0.018)), 'small': (0.005, (0.02, 0.018))}
+
+
+def condition_weights(variant: str, weights: Dict[str, np.ndarray]) -> 'OrderedDict[str, np.ndarray]':
+    """Copy of ``weights`` with ``update_block/flow_head/conv2`` scaled / biased per ``CONDITIONED_HEAD``."""
+    scale, bias = CONDITIONED_HEAD[variant]
+    w = OrderedDict(weights)
+    k = 'update_block/flow_head/conv2/'
+    w[k + 'kernel'] = (weights[k + 'kernel'] * np.float32(scale)).astype(np.float32)
+    w[k + 'bias'] = np.asarray(bias, dtype=np.float32)
+    return w
+
+
 def count_params(weights: Dict[str, np.ndarray], prefix: str = '') -> int:
     return int(sum(v.size for k, v in weights.items() if k.startswith(prefix)))
 

@@ -12,6 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tf_raft_amd import _dev, packing          # noqa: E402
 from tf_raft_amd._ffi import check             # noqa: E402
 
+
+def _ffi_opt(name, value):
+    from tf_raft_amd import _ffi
+    _ffi.set_option(name, value)   # tuning switch of the library (include/raft_hip.h)
+
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 H, W = 56, 64
 LAYERS = [  # name, kh, kw, cin(real), cin(pad), cout
@@ -31,12 +36,12 @@ for name, kh, kw, cin, cpad, cout in LAYERS:
     row = []
     for tile in ('3', '5', '141', '142', '171', '172', '181', '182', 'auto'):
         if tile == 'auto':
-            os.environ.pop('RAFT_CONV_TILE', None)
+            _ffi_opt('RAFT_CONV_TILE', '')
         else:
             if npad % ({'3': 64, '5': 64}.get(tile) or 64 * int(tile[-1])):
                 row.append(f'{tile}:   n/a')
                 continue
-            os.environ['RAFT_CONV_TILE'] = tile
+            _ffi_opt('RAFT_CONV_TILE', tile)
 
         def run():
             check(lib.raft_conv2d_f32(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W,
@@ -57,7 +62,7 @@ for name, kh, kw, cin, cpad, cout in LAYERS:
         wpw, bw, npw = packing.pack_conv_winograd(k, np.zeros(cout, np.float32), [(cin, cpad)])
         wpw_d, bw_d = _dev.to_device(wpw), _dev.to_device(bw)
         for tnw in ('1', '2'):
-            os.environ['RAFT_WINO_TNW'] = tnw
+            _ffi_opt('RAFT_WINO_TNW', tnw)
 
             def runw():
                 check(lib.raft_conv2d_winograd_f32(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wpw_d), _dev.ptr(bw_d), B, H, W,
@@ -73,12 +78,12 @@ for name, kh, kw, cin, cpad, cout in LAYERS:
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 20
             row.append(f'wino{tnw}:{flops / ms / 1e9:6.1f}TF {ms*1e3:6.1f}us')
-        os.environ.pop('RAFT_WINO_TNW', None)
+        _ffi_opt('RAFT_WINO_TNW', '')
     if kh * kw == 5:             # 1-D Winograd F(2, 5) kernel
         wpw, bw, npw = packing.pack_conv_winograd1d(k, np.zeros(cout, np.float32), [(cin, cpad)])
         wpw_d, bw_d = _dev.to_device(wpw), _dev.to_device(bw)
         for tnw in ('1', '2'):
-            os.environ['RAFT_WINO_TNW'] = tnw
+            _ffi_opt('RAFT_WINO_TNW', tnw)
 
             def runw():
                 check(lib.raft_conv1d_winograd_f32(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wpw_d), _dev.ptr(bw_d), B, H, W,
@@ -94,6 +99,6 @@ for name, kh, kw, cin, cpad, cout in LAYERS:
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 20
             row.append(f'wino{tnw}:{flops / ms / 1e9:6.1f}TF {ms*1e3:6.1f}us')
-        os.environ.pop('RAFT_WINO_TNW', None)
+        _ffi_opt('RAFT_WINO_TNW', '')
     print(f'{name:10s} K={kh*kw*cin:5d} N={cout:4d} | ' + ' | '.join(row), flush=True)
-os.environ.pop('RAFT_CONV_TILE', None)
+_ffi_opt('RAFT_CONV_TILE', '')

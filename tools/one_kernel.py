@@ -15,6 +15,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tf_raft_amd import _dev, packing          # noqa: E402
 from tf_raft_amd._ffi import check             # noqa: E402
 
+
+def _ffi_opt(name, value):
+    from tf_raft_amd import _ffi
+    _ffi.set_option(name, value)   # tuning switch of the library (include/raft_hip.h)
+
 LAYERS = {  # name: kh, kw, cin(real), cin(pad), cout
     'convc1': (1, 1, 324, 352, 256), 'convc2': (3, 3, 256, 256, 192), 'convf2': (3, 3, 128, 128, 64),
     'conv': (3, 3, 256, 256, 126), 'gru_zr': (1, 5, 256, 256, 256), 'gru_q': (1, 5, 256, 256, 128),
@@ -45,7 +50,7 @@ def main():
         reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
         kh, kw, cin, cpad, cout = LAYERS[name]
         if tile != 'auto':
-            os.environ['RAFT_CONV_TILE'] = tile
+            _ffi_opt('RAFT_CONV_TILE', tile)
         k = (rng.normal(size=(kh, kw, cin, cout)) * 0.05).astype(np.float32)
         wp, b, npad = packing.pack_conv(k, np.zeros(cout, np.float32), [(cin, cpad)])
         x = _dev.to_device(rng.normal(size=(B, H, W, cpad)).astype(np.float32))
@@ -64,7 +69,7 @@ def main():
         reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
         kh, kw, cin, cpad, cout = LAYERS[name]
         assert kh == 3 and kw == 3
-        os.environ['RAFT_WINO_TNW'] = tnw
+        _ffi_opt('RAFT_WINO_TNW', tnw)
         k = (rng.normal(size=(kh, kw, cin, cout)) * 0.05).astype(np.float32)
         wp, b, npad = packing.pack_conv_winograd(k, np.zeros(cout, np.float32), [(cin, cpad)])
         x = _dev.to_device(rng.normal(size=(B, H, W, cpad)).astype(np.float32))
@@ -81,7 +86,7 @@ def main():
         ver = sys.argv[2]
         B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
         reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-        os.environ["RAFT_LOOKUP_STAGED"] = "0" if ver in ("v3", "direct") else "1"
+        _ffi_opt("RAFT_LOOKUP_STAGED", "0" if ver in ("v3", "direct") else "1")
         from tf_raft_amd.layers.corr import CorrBlock
         f1 = rng.normal(size=(B, H, W, 256)).astype(np.float32)
         f2 = rng.normal(size=(B, H, W, 256)).astype(np.float32)

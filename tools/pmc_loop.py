@@ -1,0 +1,23 @@
+"""Workload of the PMC passes (tools/pmc_traffic.sh): ONE full forward (encoders, volume build, state preparation) and
+then the SINGLE-STREAM prediction loop, `iters` iterations, at batch B -- launch order inside an iteration is fixed
+(bench.py STAGES), which is how tools/pmc_traffic.py attributes dispatches to stages.
+usage: python tools/pmc_loop.py <batch> <iters>"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tf_raft_amd  # noqa: E402
+
+B, iters = int(sys.argv[1]), int(sys.argv[2])
+dev = torch.device('cuda', 0)
+gen = torch.Generator(device=dev)
+gen.manual_seed(1000)
+i1 = torch.rand((B, 448, 512, 3), device=dev, generator=gen) * 255.0
+i2 = torch.rand((B, 448, 512, 3), device=dev, generator=gen) * 255.0
+model = tf_raft_amd.RAFT(iters_pred=iters, overlap=False)
+out = model([i1, i2])
+torch.cuda.synchronize()
+print('done', float(out[-1].abs().max()))
