@@ -41,8 +41,8 @@
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x4 query blocks on MFMA         (default 1)
- *   RAFT_LOOP_GRAPH     0/1  three-stream loops replayed as one hipGraph launch                  (default: 1 up to
- *                       B*h*w = 7168 pixels, 0 above)
+ *   RAFT_LOOP_GRAPH     0/1  three-stream loops replayed as one hipGraph launch                  (default 0: measured
+ *                       slower than stream launches on ROCm 7.2 at every batch size)
  */
 #ifndef RAFT_HIP_H_
 #define RAFT_HIP_H_
@@ -286,7 +286,7 @@ int raft_loop_ctx_destroy(raft_loop_ctx *ctx);
  * convex upsample) run on the caller-owned side streams aux0 / aux1 next to the main chain on `stream`,
  * ordered by events; everything is joined back into `stream` before the call returns (it still only
  * enqueues).  Results are identical to raft_iterate_basic_f32.
- * With RAFT_LOOP_GRAPH on (default for small batches) the first call with a given set of arguments (pointers, sizes,
+ * With RAFT_LOOP_GRAPH on (off by default) the first call with a given set of arguments (pointers, sizes,
  * streams) captures these launches into a hipGraph kept in `ctx`; later calls with the same arguments replay it with ONE
  * hipGraphLaunch on `stream` -- the reference's canonical (1,448,512,3) call is bound by the host's ~350 launches + ~100
  * event operations otherwise.  A non-NULL `stream` is required for that (the legacy default stream cannot be captured;

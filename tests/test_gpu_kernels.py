@@ -223,8 +223,12 @@ def test_corr_lookup_ondemand_matches_oracle(rng, shape, C, sigma):
                nonzero=float((want != 0).mean()))
         assert got.shape == want.shape
         assert err <= 2e-5 * scale
-        # the zero pattern of the sampler (integer / clamped taps) must be reproduced exactly
-        np.testing.assert_array_equal(got == 0, want == 0)
+        # the zero pattern of the sampler (integer / clamped taps) must be reproduced: structural zeros are
+        # exact zeros in both; a NON-structural value may cancel to exactly 0 in one summation order only (probability
+        # ~1e-7 per element), so a handful of mismatches is tolerated -- never a whole tap row / column
+        assert int(((got == 0) != (want == 0)).sum()) <= 4
+        if name == 'integer_grid':
+            assert np.all(got[..., :(2 * radius + 1) ** 2] == 0.0)       # level 0 on the integer grid: identically 0
 
 
 @pytest.mark.parametrize('shape', [(2, 7, 9), (1, 6, 8), (3, 2, 1)])   # odd width: the last pixel pair is half empty

@@ -816,13 +816,12 @@ static void copy_weights_clean(raft_basic_update_weights *dst, const raft_basic_
 }
 
 // RAFT_LOOP_GRAPH (raft_set_option): 1 = replay the loop as ONE hipGraph launch (captured from the same enqueue code the
-// first time a given set of arguments is seen, then cached in the caller's raft_loop_ctx), 0 = enqueue ~350 kernels and
-// ~100 event operations from the host every call.  Default: graphs for small batches (B * h * w <= 2 * 3584 pixels: the
-// kernels there are shorter than the host's per-launch cost), plain launches above -- DESIGN.md section 4.2.
-static bool use_loop_graph(int B, int h, int w) {
-    const int dflt = (int64_t)B * h * w <= 2 * 3584 ? 1 : 0;
-    return raft_opt(RAFT_OPT_LOOP_GRAPH, dflt) != 0;
-}
+// first time a given set of arguments is seen, then cached in the caller's raft_loop_ctx), 0 = enqueue the ~350 kernels
+// and ~100 event operations from the host every call.  Default 0: measured on MI355X / ROCm 7.2 the replay is SLOWER
+// than the stream launches at every batch size (B = 1: 8.44 vs 7.94 ms, B = 4: 15.9 vs 15.4 ms,
+// profiles/r05a_batch_sweep.txt) -- the host is not the limiter of the small-batch loop, the dependent chain of short
+// kernels on the GPU is.  Kept as a switch: bit-identical results, one launch per forward.
+static bool use_loop_graph(int, int, int) { return raft_opt(RAFT_OPT_LOOP_GRAPH, 0) != 0; }
 
 static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, const LookupSource &src, int B, int h, int w,
                                       int iters, const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1,

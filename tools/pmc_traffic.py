@@ -55,6 +55,8 @@ def attribute(rows):
         elif 'fmap_' in name:
             out['corr_build_fmap_pyramid'].append(v)
     loop = rows[first:]
+    last = max(i for i, r in enumerate(loop) if 'upsample_convex' in r[1])     # torch reductions of the caller follow
+    loop = loop[:last + 1]
     assert len(loop) % len(STAGES) == 0, (len(loop), 'dispatches in the loop is not a multiple of the stage count')
     for i, (_, name, v) in enumerate(loop):
         st = STAGES[i % len(STAGES)]
@@ -87,7 +89,7 @@ def main():
                    'hbm_bytes_per_launch': int(round(hbm)), 'launches_averaged': len(fetch[st]),
                    'algorithmic_bytes_per_pair': alg.get(st),
                    'algorithmic_bytes_per_launch': alg[st] * batch if st in alg else None,
-                   'source': f'tools/pmc_traffic.sh: in-loop --pmc pass at B={batch}'}
+                   'source': f'{os.path.basename(sys.argv[4]) if len(sys.argv) > 4 else ""} (tools/pmc_traffic.sh, in-loop --pmc passes at B={batch})'}
         rows.append([st, batch, round(f, 1), round(wv, 1), int(round(hbm)), alg[st] * batch if st in alg else '',
                      round(hbm / (alg[st] * batch), 3) if st in alg else ''])
     with open(out_json, 'w') as fh:
