@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 200          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 201          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -397,6 +397,43 @@ int raft_flow_metrics_f32(const float *flow_gt, const unsigned char *valid, cons
 int raft_sequence_loss_f32(const float *flow_gt, const unsigned char *valid, const float *preds,
                            int64_t pred_stride, int n_predictions, int64_t npix, double gamma, float max_flow,
                            float *loss_out, double *workspace, void *stream);
+
+/* ------------------------------------------------------------------ training step, first slice (backward kernels) */
+
+/* The reference's train_step (model.py:126-144) differentiates the forward pass with tf.GradientTape.  These entry points
+ * are the backward of the path-specific ops, deterministic (no atomics).  BASELINE config 5; see DESIGN.md section 9 for
+ * what is and is not built yet. */
+
+/* d sequence_loss / d prediction_i for all n predictions (losses.py:4-21):
+ *   d_preds[i][e] = upstream * gamma^(n-i-1) * valid'[pixel(e)] * sign(pred_i[e] - flow_gt[e]) / (2 * npix),  sign(0) = 0.
+ * d_preds has the layout of preds (prediction i at d_preds + i * pred_stride). */
+int raft_sequence_loss_grad_f32(const float *flow_gt, const unsigned char *valid, const float *preds,
+                                int64_t pred_stride, int n_predictions, int64_t npix, double gamma, float max_flow,
+                                float upstream, float *d_preds, void *stream);
+
+/* Backward of raft_corr_lookup_f32 (CorrBlock.retrieve + bilinear_sampler, corr.py:116-152, 28-69), with TensorFlow's
+ * gradient conventions: floor / ceil contribute nothing, clip_by_value passes the gradient on [0, size - 1].
+ * d_out: (B, h, w, ld_out) upstream gradient of the lookup output (first levels*(2r+1)^2 channels used).
+ * d_coords: (B, h, w, 2), overwritten.  d_pyr: gradient w.r.t. the correlation pyramid in the layout of `pyr`
+ * (raft_corr_pyramid_layout), ACCUMULATED (+=) so that the iterations of the loop add up -- zero it before the first
+ * call; NULL skips it. */
+int raft_corr_lookup_backward_f32(const float *pyr, const int64_t *level_offsets, const float *coords,
+                                  const float *d_out, int ld_out, int B, int h, int w, int levels, int radius,
+                                  float *d_coords, float *d_pyr, void *stream);
+
+/* dx = dy where y > 0 else 0 (the relu between the convolutions of the update block), n elements. */
+int raft_relu_backward_f32(const float *y, const float *dy, float *dx, int64_t n, void *stream);
+
+/* Keras Conv2D (stride 1, 'same'; kh x kw in {1x1, 3x3, 1x5, 5x1}) backward w.r.t. kernel and bias:
+ *   d_kernel[ky][kx][ci][co] = sum_pixels x[b, y + ky - (kh-1)/2, x + kx - (kw-1)/2, ci] * dy[b, y, x, co]   (Keras layout)
+ *   d_bias[co] = sum_pixels dy[b, y, x, co]                                                       (NULL skips it)
+ * x: (B, H, W, ldx) with cin channels used, dy: (B, H, W, ldy) with cout channels used; cin, cout, ldx, ldy multiples
+ * of 4.  fp32 MFMA over pixel slices + an ordered second-stage sum (deterministic); workspace:
+ * raft_conv2d_wgrad_workspace_floats() floats.  The gradient w.r.t. the INPUT is raft_conv2d_f32 of dy with the flipped,
+ * transposed kernel (tf_raft_amd/packing.py pack_conv_dgrad). */
+int64_t raft_conv2d_wgrad_workspace_floats(int cin, int cout, int B, int H, int W, int kh, int kw);
+int raft_conv2d_wgrad_f32(const float *x, int ldx, int cin, const float *dy, int ldy, int cout, int B, int H, int W,
+                          int kh, int kw, float *d_kernel, float *d_bias, float *workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,144 @@
+"""First slice of the training step (reference model.py:126-144, BASELINE config 5): the backward HIP kernels of
+``tf_raft_amd.grad`` against torch autograd through the CPU ORACLE's forward functions (``oracle.sequence_loss`` restated
+with torch ops, ``oracle.CorrBlock.retrieve``, ``oracle.tf_ops.conv2d``).  GPU only.
+
+Tolerances: the loss gradient is exact up to one rounding; the lookup's coordinate gradient sums 324 products per pixel
+(fp32, different order than autograd): 1e-5 relative to its scale; the pyramid gradient is a sum of at most 4 weight
+products: 1e-6 absolute per unit upstream; convolution gradients are long fp32 dot products over pixels: compared with
+float64 autograd at 2e-5 x sqrt(K) scale (reported)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def _torch_sequence_loss(flow_gt, valid, preds, gamma, max_flow):
+    """oracle/losses.py sequence_loss (reference losses.py:4-21) with torch ops, so autograd can differentiate it."""
+    mag = torch.sqrt((flow_gt ** 2).sum(-1))
+    v = (valid & (mag < max_flow)).to(flow_gt.dtype)[..., None]
+    n = len(preds)
+    loss = 0.0
+    for i, p in enumerate(preds):
+        loss = loss + gamma ** (n - i - 1) * torch.mean(v * torch.abs(p - flow_gt))
+    return loss
+
+
+@pytest.mark.parametrize('shape,n_pred', [((1, 5, 7), 1), ((2, 64, 96), 12), ((1, 368, 496), 12)])
+def test_sequence_loss_grad_matches_autograd(rng, shape, n_pred):
+    from oracle import losses as oracle
+    from tf_raft_amd import grad
+    flow_gt = (rng.normal(size=shape + (2,)) * 4).astype(np.float32)
+    flow_gt.reshape(-1, 2)[::53] *= 200.0                      # beyond max_flow: masked
+    valid = rng.uniform(size=shape) < 0.8
+    preds = [(flow_gt + rng.normal(size=shape + (2,)) * (3.0 / (i + 1))).astype(np.float32) for i in range(n_pred)]
+    preds[0][0, 0, 0, 0] = flow_gt[0, 0, 0, 0]                 # |.| at 0: gradient 0 in TF and in torch
+    tp = [torch.tensor(p, dtype=torch.float64, requires_grad=True) for p in preds]
+    loss = _torch_sequence_loss(torch.tensor(flow_gt, dtype=torch.float64), torch.tensor(valid), tp, 0.8, 400)
+    np.testing.assert_allclose(float(loss), oracle.sequence_loss((flow_gt, valid), preds), rtol=1e-5)   # same function
+    loss.backward()
+    got = grad.sequence_loss_grad((flow_gt, valid), preds, gamma=0.8, max_flow=400)
+    assert len(got) == n_pred
+    worst = 0.0
+    for g, t in zip(got, tp):
+        want = t.grad.numpy()
+        worst = max(worst, float(np.abs(_np(g) - want).max() / max(np.abs(want).max(), 1e-30)))
+    report(f'sequence_loss grad {shape} n={n_pred}', worst_rel=worst)
+    assert worst <= 1e-6
+    assert _np(got[0])[0, 0, 0, 0] == 0.0
+    scaled = grad.sequence_loss_grad((flow_gt, valid), preds, upstream=2.5)
+    np.testing.assert_allclose(_np(scaled[-1]), 2.5 * _np(got[-1]), rtol=1e-6)
+
+
+@pytest.mark.parametrize('radius,shape,sigma', [(4, (2, 8, 12, 32), 2.0), (4, (1, 16, 24, 32), 40.0), (3, (1, 16, 24, 32), 1.0),
+                                               (4, (1, 46, 62, 32), 3.0)])
+def test_corr_lookup_backward_matches_autograd(rng, radius, shape, sigma):
+    """(1, 46, 62) is the feature-map size of the reference's 368 x 496 training crops (configs/train_chairs.yml)."""
+    import oracle
+    from tf_raft_amd import grad
+    from tf_raft_amd.layers.corr import CorrBlock
+    B, h, w, C = shape
+    f1 = rng.normal(size=shape).astype(np.float32)
+    f2 = rng.normal(size=shape).astype(np.float32)
+    dev = CorrBlock(f1, f2, 4, radius)
+    ref = oracle.CorrBlock(torch.tensor(f1, dtype=torch.float64), torch.tensor(f2, dtype=torch.float64), 4, radius)
+    pyr = [lvl.detach().clone().requires_grad_(True) for lvl in ref.corr_pyramid]
+    ref.corr_pyramid = pyr
+    for l in range(4):
+        dev._set_level(l, pyr[l].detach().to(torch.float32))    # the same volume on both sides
+    grid = oracle.coords_grid(B, h, w).numpy()
+    coords_np = (grid + rng.normal(scale=sigma, size=grid.shape)).astype(np.float32)
+    coords_np[0, 0, 0] = [3.0, 2.5]                              # an exactly integer x: zero weights, zero gradient
+    coords = torch.tensor(coords_np, dtype=torch.float64, requires_grad=True)
+    out = ref.retrieve(coords)
+    d_out = rng.normal(size=tuple(out.shape)).astype(np.float32)
+    out.backward(torch.tensor(d_out, dtype=torch.float64))
+    d_coords, d_pyr = grad.corr_lookup_backward(dev, coords_np, d_out)
+    want_c = coords.grad.numpy()
+    err_c = float(np.abs(_np(d_coords) - want_c).max())
+    scale_c = float(np.abs(want_c).max())
+    report(f'lookup backward r={radius} {shape} sigma={sigma} coords', max_abs=err_c, scale=scale_c)
+    assert err_c <= 1e-5 * max(1.0, scale_c)
+    levels = dev.untile_pyramid(d_pyr)
+    for l in range(4):
+        want = pyr[l].grad.numpy()
+        err = float(np.abs(_np(levels[l]) - want).max())
+        report(f'lookup backward r={radius} {shape} level {l} pyramid', max_abs=err, scale=float(np.abs(want).max()),
+               nonzero=float((want != 0).mean()))
+        assert err <= 2e-6 * max(1.0, float(np.abs(want).max()))
+    # accumulation over loop iterations: a second call adds to the same buffer; coords-only mode leaves it alone
+    before = d_pyr.clone()
+    _, d_pyr2 = grad.corr_lookup_backward(dev, coords_np, d_out, d_pyramid=d_pyr)
+    assert d_pyr2 is d_pyr
+    np.testing.assert_allclose(_np(d_pyr), 2 * _np(before), rtol=1e-6, atol=1e-7)
+    dc2, none = grad.corr_lookup_backward(dev, coords_np, d_out, want_pyramid_grad=False)
+    assert none is None
+    np.testing.assert_array_equal(_np(dc2), _np(d_coords))      # deterministic
+
+
+@pytest.mark.parametrize('ksize,cin,cout,shape,relu', [((3, 3), 128, 64, (2, 9, 13), True), ((1, 1), 324 + 28, 256, (1, 8, 16), True),
+                                                         ((1, 5), 256, 128, (1, 7, 20), False), ((5, 1), 64, 192, (2, 12, 6), False),
+                                                         ((3, 3), 256, 192, (1, 46, 62), True)])
+def test_conv2d_backward_matches_autograd(rng, ksize, cin, cout, shape, relu):
+    from oracle import tf_ops
+    from tf_raft_amd import grad
+    kh, kw = ksize
+    B, H, W = shape
+    x = rng.normal(size=(B, H, W, cin)).astype(np.float32)
+    kernel = (rng.normal(size=(kh, kw, cin, cout)) * 0.1).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    dy = rng.normal(size=(B, H, W, cout)).astype(np.float32)
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    tk = torch.tensor(kernel, dtype=torch.float64, requires_grad=True)
+    tb = torch.tensor(bias, dtype=torch.float64, requires_grad=True)
+    y = tf_ops.conv2d(tx, tk, tb)
+    if relu:
+        y = torch.relu(y)
+    y.backward(torch.tensor(dy, dtype=torch.float64))
+    dx, dk, db = grad.conv2d_backward(x, kernel, dy, y=y.detach().to(torch.float32).numpy() if relu else None)
+    M = B * H * W
+    for name, got, want, k_len in (('dx', dx, tx.grad, kh * kw * cout), ('d_kernel', dk, tk.grad, M), ('d_bias', db, tb.grad, M)):
+        want = want.numpy()
+        err = float(np.abs(_np(got) - want).max())
+        tol = 2e-5 * max(1.0, float(np.abs(want).max())) * max(1.0, np.sqrt(k_len) / 32)
+        report(f'conv backward {ksize} {cin}->{cout} {shape} {name}', max_abs=err, scale=float(np.abs(want).max()), tol=tol)
+        assert got.shape == want.shape
+        assert err <= tol
+    dx2, dk2, db2 = grad.conv2d_backward(x, kernel, dy, y=y.detach().to(torch.float32).numpy() if relu else None)
+    np.testing.assert_array_equal(_np(dk2), _np(dk))             # deterministic reductions
+    np.testing.assert_array_equal(_np(db2), _np(db))
+
+
+def test_backward_argument_checks():
+    from tf_raft_amd import _dev
+    lib = _dev.lib()
+    assert lib.raft_conv2d_wgrad_f32(None, 4, 4, None, 4, 4, 1, 4, 4, 3, 3, None, None, None, None) == -1
+    assert lib.raft_conv2d_wgrad_workspace_floats(0, 4, 1, 4, 4, 3, 3) == 0
+    assert lib.raft_relu_backward_f32(None, None, None, 4, None) == -1
+    assert lib.raft_sequence_loss_grad_f32(None, None, None, 8, 1, 4, 0.8, 400.0, 1.0, None, None) == -1

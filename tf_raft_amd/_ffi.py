@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 200     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 201     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -76,6 +76,11 @@ _SIGNATURES = {
     'raft_metrics_workspace_doubles': (C.c_int64, []),
     'raft_flow_metrics_f32': (_I, [_P, _P, _P, C.c_int64, C.c_float, _P, _P, _P]),
     'raft_sequence_loss_f32': (_I, [_P, _P, _P, C.c_int64, _I, C.c_int64, C.c_double, C.c_float, _P, _P, _P]),
+    'raft_sequence_loss_grad_f32': (_I, [_P, _P, _P, C.c_int64, _I, C.c_int64, C.c_double, C.c_float, C.c_float, _P, _P]),
+    'raft_corr_lookup_backward_f32': (_I, [_P, c_i64_p, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'raft_relu_backward_f32': (_I, [_P, _P, _P, C.c_int64, _P]),
+    'raft_conv2d_wgrad_workspace_floats': (C.c_int64, [_I, _I, _I, _I, _I, _I, _I]),
+    'raft_conv2d_wgrad_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'raft_conv2d_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I,
                              C.c_float, _P, _I, _P]),
     'raft_conv2d_winograd_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),

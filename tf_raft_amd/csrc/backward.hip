@@ -1,0 +1,399 @@
+// First slice of the training step (reference tf_raft/model.py:126-144 under tf.GradientTape), gfx950:
+//
+//   raft_sequence_loss_grad_f32    d sequence_loss / d prediction_i                       [losses.py:4-21]
+//   raft_corr_lookup_backward_f32  backward of CorrBlock.retrieve + bilinear_sampler: gradient w.r.t. the lookup
+//                                  coordinates and w.r.t. the correlation pyramid           [corr.py:116-152, 28-69]
+//   raft_conv2d_wgrad_f32          d Conv2D / d kernel and d bias (stride 1, 'same')       [update.py:10-11, 91-95, 138-140]
+//   raft_relu_backward_f32         dy * (y > 0)
+// (d Conv2D / d input needs no kernel of its own: it is the forward convolution of dy with the spatially flipped,
+//  in/out-transposed kernel -- tf_raft_amd/packing.py pack_conv_dgrad + raft_conv2d_f32.)
+//
+// All reductions are deterministic: no atomics anywhere; a correlation map is owned by its query (one wavefront), weight
+// gradients are split over pixel slices into a workspace and added in slice order by a second kernel.
+#include "common.h"
+#include "lookup_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// sequence_loss backward: loss = sum_i w_i * mean over 2*npix elements of m * |p_i - g|, w_i = gamma^(n-i-1)
+//   d loss / d p_i[e] = upstream * w_i * m * sign(p_i[e] - g[e]) / (2 * npix)        (sign(0) = 0, as tf.abs)
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int MAX_PRED = 64;
+struct LossWeights {
+    float w[MAX_PRED];
+};
+
+__global__ void __launch_bounds__(256) sequence_loss_grad_kernel(const float2 *__restrict__ gt, const unsigned char *__restrict__ valid,
+                                                                  const float2 *__restrict__ preds, int64_t pred_stride, int n_pred,
+                                                                  int64_t npix, float max_flow, LossWeights lw,
+                                                                  float2 *__restrict__ d_preds) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const float2 g = gt[i];
+    const float mag = sqrtf(g.x * g.x + g.y * g.y);                       // losses.py:11
+    const float m = (valid[i] != 0 && mag < max_flow) ? 1.0f : 0.0f;
+    auto sgn = [](float v) { return v > 0.f ? 1.0f : (v < 0.f ? -1.0f : 0.0f); };
+    for (int k = 0; k < n_pred; ++k) {
+        const float2 p = preds[(int64_t)k * pred_stride + i];
+        d_preds[(int64_t)k * pred_stride + i] = make_float2(lw.w[k] * m * sgn(p.x - g.x), lw.w[k] * m * sgn(p.y - g.y));
+    }
+}
+}   // namespace
+
+extern "C" int raft_sequence_loss_grad_f32(const float *flow_gt, const unsigned char *valid, const float *preds,
+                                           int64_t pred_stride, int n_predictions, int64_t npix, double gamma, float max_flow,
+                                           float upstream, float *d_preds, void *stream) {
+    RAFT_REQUIRE_PTR(flow_gt);
+    RAFT_REQUIRE_PTR(valid);
+    RAFT_REQUIRE_PTR(preds);
+    RAFT_REQUIRE_PTR(d_preds);
+    RAFT_REQUIRE(npix > 0 && n_predictions > 0 && pred_stride >= npix * 2, RAFT_E_SHAPE);
+    RAFT_REQUIRE(n_predictions <= MAX_PRED && (pred_stride & 1) == 0, RAFT_E_UNSUPPORTED);
+    RAFT_REQUIRE(((uintptr_t)flow_gt & 7) == 0 && ((uintptr_t)preds & 7) == 0 && ((uintptr_t)d_preds & 7) == 0, RAFT_E_ALIGN);
+    LossWeights lw = {};
+    for (int i = 0; i < n_predictions; ++i) {
+        double w = 1.0;
+        for (int k = 0; k < n_predictions - i - 1; ++k) w *= gamma;
+        lw.w[i] = (float)(w * (double)upstream / (2.0 * (double)npix));
+    }
+    sequence_loss_grad_kernel<<<raft_ceil_div(npix, 256), 256, 0, (hipStream_t)stream>>>(
+        (const float2 *)flow_gt, valid, (const float2 *)preds, pred_stride / 2, n_predictions, npix, max_flow, lw,
+        (float2 *)d_preds);
+    return raft_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// corr_lookup backward.  Forward (corr.py:116-152): for level l, tap (a, b):
+//   gx = clamp(x / 2^l + (a - r), 0, w_l - 1), gy likewise with b;   out = wy0 wx0 F[y0][x0] + wy0 wx1 F[y0][x1] + ...
+// with wx0 = ceil(gx) - gx, wx1 = gx - floor(gx).  Under tf.GradientTape floor / ceil have zero gradient and
+// clip_by_value passes the gradient inside [min, max] (ends included), so
+//   d out / d gx = [0 <= x/2^l + a - r <= w_l - 1] * (wy0 (F[y0][x1] - F[y0][x0]) + wy1 (F[y1][x1] - F[y1][x0])),
+//   d out / d F[yc][xc] = wyc * wxc,       d gx / d x = 2^-l.
+// One wavefront per query, levels in turn: the (2r+2)^2 footprint F and the level's (2r+1)^2 upstream gradients are
+// parked in LDS, the per-axis tap tables (index relative to the footprint origin, weights, in-range flag) are built once,
+// then  T[fx][b] = sum_a Wx[fx][a] g[a][b],  dF[fy][fx] = sum_b Wy[fy][b] T[fx][b]  (Wx[fx][a] = the weight tap a puts on
+// footprint column fx) and the coordinate gradient is reduced over the wave in a fixed order.
+// d_pyr is ACCUMULATED (+=): a map is touched by its own query's wavefront only, and the loop's iterations are ordered
+// by the stream, so plain read-modify-write is race-free and deterministic.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct LookupBwdArgs {
+    const float *pyr;
+    const float *coords;
+    const float *d_out;
+    float *d_coords;
+    float *d_pyr;     // may be NULL
+    PyramidGeom g;
+    int64_t nq;
+    int ld_out;
+};
+
+template <int R>
+__global__ void __launch_bounds__(256) corr_lookup_backward_kernel(LookupBwdArgs p) {
+    constexpr int D = 2 * R + 1, FW = 2 * R + 2, FP = FW * FW, WPB = 4;   // 4 queries (wavefronts) per workgroup
+    __shared__ float sF[WPB][FP], sG[WPB][D * D], sT[WPB][FW * D], sW[WPB][2][D][4];
+    __shared__ int sI[WPB][2][D][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * WPB + wv;
+    if (q >= p.nq) return;                                               // wave-uniform; no workgroup barrier below
+    const float2 cq = *(const float2 *)(p.coords + 2 * q);
+    float acc_x = 0.f, acc_y = 0.f;
+    for (int l = 0; l < p.g.levels; ++l) {
+        const float sc = __int_as_float((127 - l) << 23);               // 2^-l
+        const int w = p.g.lw[l], h = p.g.lh[l], tx = p.g.tx[l];
+        const int ox = axis_tap(cq.x * sc, -R, w).i0, oy = axis_tap(cq.y * sc, -R, h).i0;
+        const int64_t mbase = p.g.off[l] + q * (int64_t)p.g.map[l];
+        // footprint (clamped reads like the forward) and the level's upstream gradients
+        for (int s = lane; s < FP; s += 64) {
+            const int y = min(oy + s / FW, h - 1), x = min(ox + s % FW, w - 1);
+            sF[wv][s] = p.pyr[mbase + raft_tiled_index(y, x, tx)];
+        }
+        for (int s = lane; s < D * D; s += 64) sG[wv][s] = p.d_out[q * (int64_t)p.ld_out + l * D * D + s];
+        // per-axis tap tables: lanes 0..D-1 the x taps, lanes 32..32+D-1 the y taps
+        if ((lane & 31) < D) {
+            const int axis = lane >> 5, d = lane & 31;
+            const float c = (axis ? cq.y : cq.x) * sc;
+            const int size = axis ? h : w, o = axis ? oy : ox;
+            const AxisTap t = axis_tap(c, d - R, size);
+            const float graw = c + (float)(d - R);
+            const float in = (graw >= 0.f && graw <= (float)(size - 1)) ? 1.0f : 0.0f;   // clip_by_value gradient
+            sI[wv][axis][d][0] = t.i0 - o;
+            sI[wv][axis][d][1] = t.i1 - o;
+            sW[wv][axis][d][0] = t.w0;
+            sW[wv][axis][d][1] = t.w1;
+            sW[wv][axis][d][2] = in;
+            sW[wv][axis][d][3] = 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): this wave's LDS writes are visible to it
+        // coordinate gradient: every tap (a, b) -- a offsets x, b offsets y (corr.py:133-143), channel a * D + b
+        for (int s = lane; s < D * D; s += 64) {
+            const int a = s / D, b = s - a * D;
+            const int x0 = sI[wv][0][a][0], x1 = sI[wv][0][a][1], y0 = sI[wv][1][b][0], y1 = sI[wv][1][b][1];
+            const float wx0 = sW[wv][0][a][0], wx1 = sW[wv][0][a][1], inx = sW[wv][0][a][2];
+            const float wy0 = sW[wv][1][b][0], wy1 = sW[wv][1][b][1], iny = sW[wv][1][b][2];
+            const float v00 = sF[wv][y0 * FW + x0], v01 = sF[wv][y0 * FW + x1], v10 = sF[wv][y1 * FW + x0], v11 = sF[wv][y1 * FW + x1];
+            const float g = sG[wv][s];
+            acc_x += g * sc * inx * (wy0 * (v01 - v00) + wy1 * (v11 - v10));
+            acc_y += g * sc * iny * (wx0 * (v10 - v00) + wx1 * (v11 - v01));
+        }
+        if (p.d_pyr) {
+            // T[fx][b] = sum_a Wx[fx][a] * g[a][b]
+            for (int s = lane; s < FW * D; s += 64) {
+                const int fx = s / D, b = s - fx * D;
+                float t = 0.f;
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const float wgt = (sI[wv][0][a][0] == fx ? sW[wv][0][a][0] : 0.f) + (sI[wv][0][a][1] == fx ? sW[wv][0][a][1] : 0.f);
+                    t = fmaf(wgt, sG[wv][a * D + b], t);
+                }
+                sT[wv][s] = t;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            // dF[fy][fx] = sum_b Wy[fy][b] * T[fx][b]; positions past the border are clamped duplicates of the border
+            // pixel in the forward's footprint and are never referenced by a tap: only in-range positions are written
+            for (int s = lane; s < FP; s += 64) {
+                const int fy = s / FW, fx = s - fy * FW;
+                float dv = 0.f;
+#pragma unroll
+                for (int b = 0; b < D; ++b) {
+                    const float wgt = (sI[wv][1][b][0] == fy ? sW[wv][1][b][0] : 0.f) + (sI[wv][1][b][1] == fy ? sW[wv][1][b][1] : 0.f);
+                    dv = fmaf(wgt, sT[wv][fx * D + b], dv);
+                }
+                const int y = oy + fy, x = ox + fx;
+                if (y < h && x < w) p.d_pyr[mbase + raft_tiled_index(y, x, tx)] += dv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                 // the next level overwrites the LDS tables
+    }
+    // fixed-order butterfly: deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        acc_x += __shfl_xor(acc_x, o, 64);
+        acc_y += __shfl_xor(acc_y, o, 64);
+    }
+    if (lane == 0) *(float2 *)(p.d_coords + 2 * q) = make_float2(acc_x, acc_y);
+}
+}   // namespace
+
+extern "C" int raft_corr_lookup_backward_f32(const float *pyr, const int64_t *level_offsets, const float *coords,
+                                             const float *d_out, int ld_out, int B, int h, int w, int levels, int radius,
+                                             float *d_coords, float *d_pyr, void *stream) {
+    RAFT_REQUIRE_PTR(pyr);
+    RAFT_REQUIRE_PTR(level_offsets);
+    RAFT_REQUIRE_PTR(coords);
+    RAFT_REQUIRE_PTR(d_out);
+    RAFT_REQUIRE_PTR(d_coords);
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
+    LookupBwdArgs a;
+    RAFT_TRY(raft_make_geom(h, w, levels, level_offsets, &a.g));
+    const int d = 2 * radius + 1;
+    RAFT_REQUIRE(ld_out >= levels * d * d, RAFT_E_SHAPE);
+    a.pyr = pyr;
+    a.coords = coords;
+    a.d_out = d_out;
+    a.d_coords = d_coords;
+    a.d_pyr = d_pyr;
+    a.nq = (int64_t)B * h * w;
+    a.ld_out = ld_out;
+    const int grid = raft_ceil_div(a.nq, 4);
+    if (radius == 4)
+        corr_lookup_backward_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    else if (radius == 3)
+        corr_lookup_backward_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    else
+        return RAFT_E_UNSUPPORTED;
+    return raft_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// relu backward
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) relu_backward_kernel(const float *__restrict__ y, const float *__restrict__ dy,
+                                                            float *__restrict__ dx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+extern "C" int raft_relu_backward_f32(const float *y, const float *dy, float *dx, int64_t n, void *stream) {
+    RAFT_REQUIRE_PTR(y);
+    RAFT_REQUIRE_PTR(dy);
+    RAFT_REQUIRE_PTR(dx);
+    RAFT_REQUIRE(n > 0, RAFT_E_SHAPE);
+    relu_backward_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(y, dy, dx, n);
+    return raft_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv2D weight gradient (stride 1, 'same'), fp32 MFMA 16x16x4:
+//   dK[ky][kx][ci][co] = sum over pixels  x[b, y + ky - pt, x + kx - pl, ci] * dy[b, y, x, co]
+// a GEMM whose reduction dimension is the PIXELS.  A workgroup owns 64 input channels x 64 output channels x all kh*kw
+// taps and a slice of the 4 x 16 pixel tiles; wave w takes input channels 16 w .. 16 w + 15: kh*kw x 4 accumulator tiles.
+// Per pixel tile the x halo ((4 + kh - 1) x (16 + kw - 1) pixels x 64 channels) and the dy tile (64 pixels x 64
+// channels) are staged in LDS with an 80-float pixel stride (the four k-groups of an MFMA operand read four consecutive
+// pixels: 16 banks apart, conflict-free); an MFMA k-step is four consecutive pixels of a tile row, its A operand the
+// tap-shifted x values, its B operand dy -- dy fragments are read once per k-step and reused by every tap.
+// Partial sums go to workspace[slice][tap][ci][co]; wgrad_reduce_kernel adds the slices in order (deterministic) and
+// writes the Keras-layout kernel gradient.  The bias gradient (column sums of dy) takes the same two steps.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int WG_TH = 4, WG_TW = 16, WG_PS = 80, WG_MAXT = 9;
+
+struct WgradArgs {
+    const float *x, *dy;
+    float *part;          // [S][T][cin][cout]
+    int ldx, ldy, cin, cout, B, H, W, kh, kw, S, tiles_y, tiles_x;
+};
+
+template <int KH, int KW>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
+    constexpr int T = KH * KW, HH = WG_TH + KH - 1, HW = WG_TW + KW - 1;
+    constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;
+    static_assert(T <= WG_MAXT, "accumulator budget");
+    __shared__ __attribute__((aligned(16))) float sX[HH * HW * WG_PS];
+    __shared__ __attribute__((aligned(16))) float sY[WG_TH * WG_TW * WG_PS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int cib = blockIdx.x, cob = blockIdx.y, sl = blockIdx.z;
+    const int ci0 = cib * 64, co0 = cob * 64;
+    const int ntiles = p.B * p.tiles_y * p.tiles_x;
+    const int t_lo = (int)((long)ntiles * sl / p.S), t_hi = (int)((long)ntiles * (sl + 1) / p.S);
+
+    f32x4 acc[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        const int txi = tile % p.tiles_x, tyi = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+        const int y0 = tyi * WG_TH, x0 = txi * WG_TW;
+        __syncthreads();                                   // previous tile's fragments have been read
+        // stage x halo: items = (halo pixel, 16-byte channel quad of the 64-channel block)
+        for (int it = tid; it < HH * HW * 16; it += 256) {
+            const int hp = it >> 4, c4 = it & 15;
+            const int yy = y0 - PT + hp / HW, xx = x0 - PL + hp % HW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int c = ci0 + c4 * 4;
+            if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && c < p.cin)
+                v = *(const f32x4 *)(p.x + ((int64_t)(b * p.H + yy) * p.W + xx) * p.ldx + c);
+            *(f32x4 *)(sX + hp * WG_PS + c4 * 4) = v;
+        }
+        for (int it = tid; it < WG_TH * WG_TW * 16; it += 256) {
+            const int pp = it >> 4, c4 = it & 15;
+            const int yy = y0 + pp / WG_TW, xx = x0 + pp % WG_TW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int c = co0 + c4 * 4;
+            if (yy < p.H && xx < p.W && c < p.cout)
+                v = *(const f32x4 *)(p.dy + ((int64_t)(b * p.H + yy) * p.W + xx) * p.ldy + c);
+            *(f32x4 *)(sY + pp * WG_PS + c4 * 4) = v;
+        }
+        __syncthreads();
+        // k-steps: 4 consecutive pixels of a tile row; lane (r, g): pixel 4 * step + g
+#pragma unroll 2
+        for (int step = 0; step < WG_TH * WG_TW / 4; ++step) {
+            const int pp = step * 4 + g, py = pp / WG_TW, px = pp % WG_TW;
+            float bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = sY[pp * WG_PS + j * 16 + r];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int ky = t / KW, kx = t % KW;
+                const float av = sX[((py + ky) * HW + px + kx) * WG_PS + wv * 16 + r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[j], acc[t][j], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = ci][col = co]: lane (col = r, rows 4 g + e)
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = ci0 + wv * 16 + 4 * g + e, co = co0 + j * 16 + r;
+                if (ci < p.cin && co < p.cout)
+                    p.part[(((int64_t)sl * T + t) * p.cin + ci) * p.cout + co] = acc[t][j][e];
+            }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int S, int64_t n, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(int64_t)k * n + i];
+    out[i] = s;
+}
+
+// column sums of dy: partial[blk][co] over a pixel range, then the same ordered reduction
+__global__ void __launch_bounds__(256) bias_grad_partial_kernel(const float *__restrict__ dy, int ldy, int cout, int64_t M, int nblk,
+                                                                float *__restrict__ part) {
+    const int blk = blockIdx.x;
+    const int64_t lo = M * blk / nblk, hi = M * (blk + 1) / nblk;
+    for (int c = threadIdx.x; c < cout; c += 256) {
+        float s = 0.f;
+        for (int64_t m = lo; m < hi; ++m) s += dy[m * ldy + c];
+        part[(int64_t)blk * cout + c] = s;
+    }
+}
+
+int wgrad_slices(int cin, int cout, int B, int H, int W) {
+    const int ntiles = B * ((H + WG_TH - 1) / WG_TH) * ((W + WG_TW - 1) / WG_TW);
+    const int blocks = ((cin + 63) / 64) * ((cout + 63) / 64);
+    int S = (1024 + blocks - 1) / blocks;                  // about four workgroups per CU
+    if (S > ntiles) S = ntiles;
+    if (S > 128) S = 128;
+    return S < 1 ? 1 : S;
+}
+constexpr int BIAS_BLOCKS = 256;
+}   // namespace
+
+extern "C" int64_t raft_conv2d_wgrad_workspace_floats(int cin, int cout, int B, int H, int W, int kh, int kw) {
+    if (cin <= 0 || cout <= 0 || B <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (int64_t)wgrad_slices(cin, cout, B, H, W) * kh * kw * cin * cout + (int64_t)BIAS_BLOCKS * cout;
+}
+
+extern "C" int raft_conv2d_wgrad_f32(const float *x, int ldx, int cin, const float *dy, int ldy, int cout, int B, int H, int W,
+                                     int kh, int kw, float *d_kernel, float *d_bias, float *workspace, void *stream) {
+    RAFT_REQUIRE_PTR(x);
+    RAFT_REQUIRE_PTR(dy);
+    RAFT_REQUIRE_PTR(d_kernel);
+    RAFT_REQUIRE_PTR(workspace);
+    RAFT_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, RAFT_E_SHAPE);
+    RAFT_REQUIRE(cin % 4 == 0 && cout % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, RAFT_E_UNSUPPORTED);
+    RAFT_REQUIRE(raft_aligned16(x) && raft_aligned16(dy), RAFT_E_ALIGN);
+    hipStream_t s = (hipStream_t)stream;
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.part = workspace;
+    a.ldx = ldx; a.ldy = ldy; a.cin = cin; a.cout = cout; a.B = B; a.H = H; a.W = W; a.kh = kh; a.kw = kw;
+    a.S = wgrad_slices(cin, cout, B, H, W);
+    a.tiles_y = (H + WG_TH - 1) / WG_TH;
+    a.tiles_x = (W + WG_TW - 1) / WG_TW;
+    const dim3 grid((cin + 63) / 64, (cout + 63) / 64, a.S);
+    if (kh == 1 && kw == 1)
+        conv_wgrad_kernel<1, 1><<<grid, 256, 0, s>>>(a);
+    else if (kh == 3 && kw == 3)
+        conv_wgrad_kernel<3, 3><<<grid, 256, 0, s>>>(a);
+    else if (kh == 1 && kw == 5)
+        conv_wgrad_kernel<1, 5><<<grid, 256, 0, s>>>(a);
+    else if (kh == 5 && kw == 1)
+        conv_wgrad_kernel<5, 1><<<grid, 256, 0, s>>>(a);
+    else
+        return RAFT_E_UNSUPPORTED;
+    RAFT_TRY(raft_launch_status());
+    const int64_t n = (int64_t)kh * kw * cin * cout;
+    wgrad_reduce_kernel<<<raft_ceil_div(n, 256), 256, 0, s>>>(workspace, a.S, n, d_kernel);
+    RAFT_TRY(raft_launch_status());
+    if (d_bias) {
+        float *bp = workspace + (int64_t)a.S * n;
+        const int64_t M = (int64_t)B * H * W;
+        bias_grad_partial_kernel<<<BIAS_BLOCKS, 256, 0, s>>>(dy, ldy, cout, M, BIAS_BLOCKS, bp);
+        RAFT_TRY(raft_launch_status());
+        wgrad_reduce_kernel<<<raft_ceil_div(cout, 256), 256, 0, s>>>(bp, BIAS_BLOCKS, cout, d_bias);
+        RAFT_TRY(raft_launch_status());
+    }
+    return RAFT_OK;
+}

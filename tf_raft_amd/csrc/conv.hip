@@ -213,7 +213,10 @@ constexpr int RAFT_GRU_WINO4_DEFAULT = 15;
 static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weights &wino, const raft_conv_weights &wino4,
                            int bit, ConvArgs a, int kh, int kw, int epi, hipStream_t s) {
     const int mask = raft_opt(RAFT_OPT_GRU_WINO, RAFT_GRU_WINO_DEFAULT);
-    const int mask4 = raft_opt(RAFT_OPT_GRU_WINO4, RAFT_GRU_WINO4_DEFAULT);
+    // F(4, 5) wins where the launch fills the chip; below ~2 x 3584 pixels (the reference's single 448 x 512 pair) every
+    // kernel is one under-filled round of workgroups and the F(2, 5) kernel's smaller workgroups finish sooner
+    // (B = 1: 8.69 -> 8.40 ms per forward, profiles/r05d_b1_probe.txt)
+    const int mask4 = raft_opt(RAFT_OPT_GRU_WINO4, (int64_t)a.B * a.H * a.W < 2 * 3584 ? 0 : RAFT_GRU_WINO4_DEFAULT);
     if ((mask4 & bit) && wino4.wp != nullptr && a.c0 % 32 == 0 && a.c1 % 32 == 0) {
         a.wp = wino4.wp;
         a.bias = wino4.bias;

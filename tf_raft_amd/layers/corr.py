@@ -132,6 +132,14 @@ class CorrBlock:
             out.append(_dev.wrap(untile_maps(flat, self._lh[l], self._lw[l]).contiguous().unsqueeze(-1)))
         return out
 
+    def untile_pyramid(self, flat):
+        """A flat tensor in the pyramid's tiled layout (e.g. the pyramid gradient of ``tf_raft_amd.grad``) as the
+        reference's list of ``(bs*h*w, h_l, w_l, 1)`` per-level maps."""
+        bs, h, w, _ = self.fmap1.shape
+        n = bs * h * w
+        return [_dev.wrap(untile_maps(flat[self._off[l]:self._off[l + 1]].view(n, -1), self._lh[l], self._lw[l])
+                          .contiguous().unsqueeze(-1)) for l in range(self.num_levels)]
+
     def _set_level(self, l, maps):
         """Overwrite level ``l`` of the stored volume with (bs*h*w, h_l, w_l[, 1]) maps (parity tests)."""
         maps = _dev.to_device(maps).reshape(-1, self._lh[l], self._lw[l])

@@ -47,6 +47,22 @@ def pack_conv(kernel: np.ndarray, bias: np.ndarray,
     return np.ascontiguousarray(wp), b, npad
 
 
+def dgrad_kernel(kernel: np.ndarray) -> np.ndarray:
+    """Kernel of the INPUT gradient of a stride-1 'same' Conv2D with odd kernel sizes: dx = conv2d(dy, K') with
+    K'[ky, kx, co, ci] = K[kh-1-ky, kw-1-kx, ci, co] (spatial flip, in/out transposed) -- the backward of reference
+    update.py:10-11, 91-95, 138-140 runs on the forward convolution kernels (``raft_conv2d_f32``)."""
+    k = np.asarray(kernel, dtype=np.float32)
+    if k.ndim != 4 or k.shape[0] % 2 == 0 or k.shape[1] % 2 == 0:
+        raise ValueError(f'dgrad_kernel expects an odd-sized (kh, kw, Cin, Cout) kernel, got {k.shape}')
+    return np.ascontiguousarray(k[::-1, ::-1].transpose(0, 1, 3, 2))
+
+
+def pack_conv_dgrad(kernel: np.ndarray, sources: Sequence[Tuple[int, int]] = None):
+    """``pack_conv`` of ``dgrad_kernel(kernel)`` with a zero bias: (wp, bias, npad) for ``raft_conv2d_f32`` applied to dy."""
+    dk = dgrad_kernel(kernel)
+    return pack_conv(dk, np.zeros((dk.shape[3],), np.float32), sources)
+
+
 # Winograd F(2x2, 3x3) weight transform (Lavin & Gray 2016): U = G g G^T
 _WINO_G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=np.float64)
 
