@@ -257,53 +257,80 @@ static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weigh
 }
 
 // ------------------------------------------------------------------------------------------------
-// convf1: 7x7, Cin = 2 (flow), relu.  K = 98 is too thin for the MFMA path and the work is 0.4 %
-// of the block, so: lane = output channel with its 98 weights held in registers, the flow halo
-// tile lives in LDS and is read as wave-uniform (broadcast) ds_read_b64.  [reference update.py:93]
+// convf1: 7x7, Cin = 2 (flow), relu -- a GEMM [pixels x 98] . [98 x COUT] on fp32 MFMA 16x16x4.  [reference update.py:93]
+// A workgroup owns 4 rows x 16 columns of pixels; wave w takes row w (one MFMA row block) and all COUT channels.  The
+// (4 + 6) x (16 + 6) x 2 flow halo tile lives in LDS (zeros outside the image = 'same' padding); a k-step is four
+// consecutive k = (ky * 7 + kx) * 2 + c of the Keras-layout kernel [k][n], so the A operand of lane (pixel r, k-group g)
+// is the halo value at (row + ky, r + kx, c) and the B operand the kernel row k, both from LDS.
+// K = 98 is padded to 100 with zero kernel rows.  The first version of this layer held the 98 weights of a lane's channel in
+// registers and walked the pixels with wave-uniform LDS reads on the VALU: 18.9 us per launch at B = 4 for 0.36 GFLOP
+// (profiles/r05b); this one is bound by its launch.
 // ------------------------------------------------------------------------------------------------
 template <int COUT>
 __global__ void __launch_bounds__(256) conv7x7_c2_kernel(const float *__restrict__ flow, const float *__restrict__ wk,
                                                          const float *__restrict__ bias, int B, int H, int W,
                                                          float *__restrict__ out, int ldo) {
-    constexpr int TP = 32;               // pixels (along x) per workgroup
-    constexpr int CG = COUT / 64;        // channel groups of 64 lanes
-    constexpr int PG = 4 / CG;           // pixel groups
+    constexpr int TH = 4, TW = 16, HW = TW + 6, NJ = COUT / 16, KQ = 25, LDW = COUT + 16;
     static_assert(COUT == 64 || COUT == 128, "conv7x7_c2: COUT must be 64 or 128");
-    __shared__ float2 sf[7][TP + 6];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int xt = (W + TP - 1) / TP;
-    const int x0 = (blockIdx.x % xt) * TP;
-    const int y = (blockIdx.x / xt) % H;
-    const int b = blockIdx.x / (xt * H);
-    for (int i = tid; i < 7 * (TP + 6); i += 256) {
-        const int r = i / (TP + 6), c = i - r * (TP + 6);
-        const int yy = y + r - 3, xx = x0 + c - 3;
-        float2 v = make_float2(0.f, 0.f);
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = ((const float2 *)flow)[((int64_t)b * H + yy) * W + xx];
-        sf[r][c] = v;
+    __shared__ float sf[(TH + 6) * HW * 2];
+    // the whole kernel [k][n], rows 98 and 99 zero; row stride COUT + 16: the four k-groups of a B fragment read rows
+    // k .. k + 3, 16 banks apart.  Staged with ONE round of coalesced loads per workgroup: fragments fetched from global
+    // memory inside the k loop serialise on their L2 round trips (one wave per SIMD, nothing to hide them behind)
+    __shared__ __attribute__((aligned(16))) float sw[4 * KQ * LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int xt = (W + TW - 1) / TW, yt = (H + TH - 1) / TH;
+    const int x0 = (blockIdx.x % xt) * TW, y0 = ((blockIdx.x / xt) % yt) * TH, b = blockIdx.x / (xt * yt);
+    {   // every load of the staging phase is issued before the first LDS write (unconditional, clamped addresses): a
+        // load / wait / store loop costs one L2 round trip per iteration -- 13 of them were most of this kernel's 16 us
+        constexpr int NW = (4 * KQ * (COUT / 4) + 255) / 256;
+        f32x4 tw[NW];
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = tid + 256 * u, k = min(i / (COUT / 4), 97), c4 = i % (COUT / 4);
+            tw[u] = *(const f32x4 *)(wk + k * COUT + c4 * 4);
+        }
+        const int i0 = tid, i1 = min(tid + 256, (TH + 6) * HW - 1);
+        const int ya = y0 - 3 + i0 / HW, xa = x0 - 3 + i0 % HW, yb = y0 - 3 + i1 / HW, xb = x0 - 3 + i1 % HW;
+        const bool oka = (unsigned)ya < (unsigned)H && (unsigned)xa < (unsigned)W;
+        const bool okb = (unsigned)yb < (unsigned)H && (unsigned)xb < (unsigned)W;
+        const float2 fa = ((const float2 *)flow)[oka ? ((int64_t)b * H + ya) * W + xa : 0];
+        const float2 fb = ((const float2 *)flow)[okb ? ((int64_t)b * H + yb) * W + xb : 0];
+        static_assert((TH + 6) * HW <= 512, "two halo items per thread");
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = tid + 256 * u, k = i / (COUT / 4), c4 = i % (COUT / 4);
+            if (k < 4 * KQ) *(f32x4 *)(sw + k * LDW + c4 * 4) = k < 98 ? tw[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (i0 < (TH + 6) * HW) ((float2 *)sf)[i0] = oka ? fa : make_float2(0.f, 0.f);
+        if (tid + 256 < (TH + 6) * HW) ((float2 *)sf)[tid + 256] = okb ? fb : make_float2(0.f, 0.f);
     }
-    const int cg = wid % CG, pg = wid / CG;
-    const int n = cg * 64 + lane;
-    float wr[98];
-#pragma unroll
-    for (int k = 0; k < 98; ++k) wr[k] = wk[k * COUT + n];
-    const float bv = bias[n];
     __syncthreads();
-    constexpr int PPW = TP / PG;         // pixels per wave
-    for (int i = 0; i < PPW; ++i) {
-        const int xl = pg * PPW + i;
-        const int x = x0 + xl;
-        if (x >= W) break;
-        float acc = bv;
+    f32x4 acc[NJ];
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky)
+    for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 5
+    for (int q = 0; q < KQ; ++q) {
+        const int k = 4 * q + g;
+        const int kk = k < 98 ? k : 0, ky = kk / 14, rem = kk - ky * 14;        // rem = kx * 2 + c; rows 98, 99 of sw are zero
+        const float av = sf[((wv + ky) * HW + r) * 2 + rem];                   // ((row + ky) * HW + r + kx) * 2 + c
+        float bv[NJ];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                const float2 f = sf[ky][xl + kx];
-                acc = fmaf(f.x, wr[(ky * 7 + kx) * 2], acc);
-                acc = fmaf(f.y, wr[(ky * 7 + kx) * 2 + 1], acc);
-            }
-        out[(((int64_t)b * H + y) * W + x) * ldo + n] = fmaxf(acc, 0.f);
+        for (int j = 0; j < NJ; ++j) bv[j] = sw[k * LDW + j * 16 + r];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[j], 0, 0, 0);
+    }
+    // D[row = pixel 4 g + e of the wave's row][col = channel 16 j + r]
+    const int y = y0 + wv;
+    if (y >= H) return;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float bj = bias[j * 16 + r];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int x = x0 + 4 * g + e;
+            if (x < W) out[(((int64_t)b * H + y) * W + x) * ldo + j * 16 + r] = fmaxf(acc[j][e] + bj, 0.f);
+        }
     }
 }
 
@@ -574,8 +601,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     if (ov) RAFT_HIP(hipStreamWaitEvent(sf, ov->e_fh, 0));   // flow of the previous iteration is final
     {   // flo = relu(convf1(flow))            7x7, 2 -> 128
-        const int xt = (w + 31) / 32;
-        conv7x7_c2_kernel<128><<<B * h * xt, 256, 0, sf>>>(st->flow, wts->convf1.wp, wts->convf1.bias, B, h, w, flo1, 128);
+        conv7x7_c2_kernel<128><<<B * ((h + 3) / 4) * ((w + 15) / 16), 256, 0, sf>>>(st->flow, wts->convf1.wp, wts->convf1.bias, B, h, w, flo1, 128);
         RAFT_TRY(raft_launch_status());
         RAFT_MARK();
     }
@@ -996,8 +1022,7 @@ extern "C" int raft_update_small_f32(const raft_small_update_weights *wts, int B
         RAFT_TRY(raft_launch_conv(a, 1, 1, EPI_RELU, s));
     }
     {   // flo = relu(convf1(flow))      7x7, 2 -> 64
-        const int xt = (w + 31) / 32;
-        conv7x7_c2_kernel<64><<<B * h * xt, 256, 0, s>>>(st->flow, wts->convf1.wp, wts->convf1.bias, B, h, w, flo1, 64);
+        conv7x7_c2_kernel<64><<<B * ((h + 3) / 4) * ((w + 15) / 16), 256, 0, s>>>(st->flow, wts->convf1.wp, wts->convf1.bias, B, h, w, flo1, 64);
         RAFT_TRY(raft_launch_status());
     }
     {   // flo = relu(convf2(flo))       3x3, 64 -> 32           -> corflo[:, 96:128]
