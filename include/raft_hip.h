@@ -37,7 +37,7 @@
  *   RAFT_WINO1D_TM      1/2  half- / full-height F(2,5) tiles                                    (default: by grid size)
  *   RAFT_ENC_TILE       "<th><tn>" halo tile of the encoder convolutions, e.g. 72                (default: by map height)
  *   RAFT_ENC_WINO       0/1  encoder ResBlock 3x3 layers on the F(2x2,3x3) kernel                 (default 1)
- *   RAFT_LOOKUP_KERNEL  0 strip kernel, 1 pair kernel (csrc/corr.hip)                            (default: see corr.hip)
+ *   RAFT_LOOKUP_FUSED   0/1  prediction loops: lookup + convc1 as two kernels / fused (raft_lookup_convc1_f32)  (default 1)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x4 query blocks on MFMA         (default 1)
@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 201          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 202          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -198,6 +198,13 @@ int raft_conv1d_winograd4_f32(const float *a0, int lda0, int c0, const float *a1
                               const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
                               int npad, int nvalid, int act, float scale, float *out, int ldo, void *stream);
 
+/* cor1 = relu(convc1(CorrBlock.retrieve(coords))) in ONE kernel (reference corr.py:116-152 + update.py:91, 98): the
+ * window values are those of raft_corr_lookup_f32 bit for bit, but they live only in LDS as the A operand of the 1x1
+ * convolution -- the (B, h, w, 324) lookup output is neither written nor re-read.  levels = 4, radius = 4, npad = 256.
+ * wp / bias: packing.py pack_convc1_fused.  out: (B*h*w, ldo), first nvalid channels written. */
+int raft_lookup_convc1_f32(const float *pyr, const int64_t *level_offsets, const float *coords, int B, int h, int w,
+                           const float *wp, const float *bias, int npad, int nvalid, float *out, int ldo, void *stream);
+
 /* ------------------------------------------------------------------ update block */
 
 typedef struct raft_conv_weights {
@@ -232,6 +239,10 @@ typedef struct raft_basic_update_weights {
     /* optional: 1-D Winograd F(4, 5) transformed copies of gru_zr{1,2} / gru_q{1,2}, packed as 8-tap kernels
      * (8, Cin/4, npad, 4) -- pack_conv_winograd1d(..., m=4); preferred over the F(2, 5) copies when supplied */
     raft_conv_weights gru_zr1_w4, gru_q1_w4, gru_zr2_w4, gru_q2_w4;
+    /* optional: convc1 repacked for raft_lookup_convc1_f32 (K = 4 levels x 84: each level's 81 channels + 3 zero rows;
+     * (84, 256, 4) -- packing.py pack_convc1_fused).  When supplied, the raft_iterate_basic_* loops on a STORED volume
+     * run the lookup fused into convc1 (RAFT_LOOKUP_FUSED = 0 keeps the two kernels). */
+    raft_conv_weights convc1_f;
 } raft_basic_update_weights;
 
 /* Device state of the recurrent loop (all caller-owned, (B*h*w) pixels, NHWC):

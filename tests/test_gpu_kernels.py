@@ -173,6 +173,46 @@ def test_corr_lookup_axis_quirk(rng):
     assert abs(got[0, 8, 8, a * 9 + b] - want) < 1e-5
 
 
+@pytest.mark.parametrize('shape,sigma', [((1, 56, 64), 3.0), ((4, 56, 64), 0.3), ((2, 9, 13), 40.0), ((1, 5, 7), 1.0)])
+def test_lookup_fused_into_convc1_matches_oracle(rng, shape, sigma):
+    """raft_lookup_convc1_f32 = relu(convc1(CorrBlock.retrieve(coords))) in one kernel (reference corr.py:116-152 +
+    update.py:91, 98).  Against the float64 oracle (lookup on the same volume, then the 1x1 convolution) at the per-kernel
+    2e-5 bound, and against the two-kernel HIP path (bit-exact lookup + direct convolution): same window values, the
+    324-long sums only differ in order.  (4, 56, 64) is the benchmarked launch; 9x13 / 5x7 have ragged last workgroups
+    (117 and 35 queries, 28 per workgroup) and degenerate pyramid levels."""
+    import oracle
+    from oracle import tf_ops
+    from tf_raft_amd import _dev, packing
+    from tf_raft_amd._ffi import check
+    B, h, w = shape
+    C = 32
+    f1 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    f2 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    levels = 4 if min(h, w) >= 8 else 3
+    if levels != 4:
+        pytest.skip('the fused kernel is instantiated for the 4-level pyramid')
+    dev, ref = _device_corr_with_oracle_pyramid(f1, f2, 4, 4)
+    grid = oracle.coords_grid(B, h, w).numpy()
+    coords = (grid + rng.normal(scale=sigma, size=grid.shape)).astype(np.float32)
+    kernel = (rng.normal(size=(1, 1, 324, 256)) * 0.1).astype(np.float32)
+    bias = rng.normal(size=(256,)).astype(np.float32)
+    wp, b, npad = packing.pack_convc1_fused(kernel, bias)
+    wp_d, b_d, c_d = _dev.to_device(wp), _dev.to_device(b), _dev.to_device(coords)
+    out = torch.full((B, h, w, 256), float('nan'), device=c_d.device)
+    check(_dev.lib().raft_lookup_convc1_f32(_dev.ptr(dev._pyr), dev._off, _dev.ptr(c_d), B, h, w, _dev.ptr(wp_d), _dev.ptr(b_d),
+                                            npad, 256, _dev.ptr(out), 256, _dev.stream_ptr()), 'lookup_convc1')
+    got = _np(out)
+    corr64 = ref.retrieve(_t(coords)).double()                      # the oracle's lookup of the SAME fp32 volume
+    want = torch.relu(tf_ops.conv2d(corr64, _t(kernel).double(), _t(bias).double())).numpy()
+    err = float(np.abs(got - want).max())
+    two = _conv_device([(_np(dev.retrieve(coords)), 352)], kernel, bias, act=1)          # lookup kernel + direct 1x1 kernel
+    report(f'lookup+convc1 fused {shape} sigma={sigma}', max_abs_vs_f64=err, scale=float(np.abs(want).max()),
+           vs_two_kernels=float(np.abs(got - two).max()))
+    assert not np.isnan(got).any()
+    assert err <= 2e-5 * max(1.0, float(np.abs(want).max()))
+    assert float(np.abs(got - two).max()) <= 2e-5 * max(1.0, float(np.abs(want).max()))
+
+
 @pytest.mark.parametrize('radius,C', [(4, 256), (3, 128)])
 # kernel: blocked MFMA (4 x 4 query blocks, default) / wave per query;  flow: smooth-ish (the bounding box of a block
 # fits) / wildly divergent (blocks fall back to one query at a time);  shapes: whole blocks / ragged edges

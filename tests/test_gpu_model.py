@@ -438,3 +438,21 @@ def test_graph_replayed_loop_is_bitwise_the_launched_loop(raft_opt):
     for x, y in zip(direct, direct_ref):
         assert np.array_equal(x, y)
     assert not np.array_equal(direct[-1], ref[0][-1])       # the direct GRU kernels round differently from F(4,5)
+
+
+def test_fused_lookup_loop_matches_two_kernel_loop(raft_opt):
+    """RAFT_LOOKUP_FUSED (default on): the loops run lookup + convc1 as one kernel.  Same window values, a differently
+    ordered 324-long sum in convc1: the predictions of the two loops agree far inside the parity tolerance on a
+    well-conditioned case, and the final-only loop (predict_step) stays bit-identical to call()[-1] in either mode."""
+    import tf_raft_amd
+    i1, i2, wts = _conditioned_case('raft', 128, 192, 1, B=2)
+    model = tf_raft_amd.RAFT(weights=wts, iters_pred=8)
+    fused = [_np(p) for p in model([i1, i2])]
+    np.testing.assert_array_equal(_np(model.predict_step((i1, i2))), fused[-1])
+    raft_opt.set('RAFT_LOOKUP_FUSED', '0')
+    two = [_np(p) for p in model([i1, i2])]
+    np.testing.assert_array_equal(_np(model.predict_step((i1, i2))), two[-1])
+    errs = [_max_epe(a, b) for a, b in zip(fused, two)]
+    report('fused vs two-kernel lookup loop', worst_epe=max(errs))
+    assert max(errs) <= 1e-4
+    assert any(not np.array_equal(a, b) for a, b in zip(fused, two))      # the switch did change the kernels

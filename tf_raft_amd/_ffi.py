@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 201     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 202     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -29,7 +29,7 @@ class BasicUpdateWeights(C.Structure):
         'fh1_mask0', 'fh2', 'mask2', 'gru_ctx1', 'gru_ctx2',
         'convc2_w', 'convf2_w', 'conv_w', 'fh1_mask0_w',
         'gru_zr1_w', 'gru_q1_w', 'gru_zr2_w', 'gru_q2_w', 'fh1_w',
-        'gru_zr1_w4', 'gru_q1_w4', 'gru_zr2_w4', 'gru_q2_w4')]
+        'gru_zr1_w4', 'gru_q1_w4', 'gru_zr2_w4', 'gru_q2_w4', 'convc1_f')]
 
 
 class SmallUpdateWeights(C.Structure):
@@ -66,6 +66,7 @@ _SIGNATURES = {
     'raft_corr_build_workspace_floats': (C.c_int64, [_I, _I, _I, _I, _I]),
     'raft_corr_build_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, c_i64_p, _P, _P]),
     'raft_corr_lookup_f32': (_I, [_P, c_i64_p, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    'raft_lookup_convc1_f32': (_I, [_P, c_i64_p, _P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P]),
     'raft_fmap_pyramid_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'raft_corr_lookup_ondemand_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     'raft_bilinear_sampler_f32': (_I, [_P, _P, C.c_int64, _I, _I, _I, _I, _P, _P]),

@@ -556,6 +556,13 @@ struct StageTimer {
         if (tm) tm->mark(s);        \
     } while (0)
 
+// Where the loop's correlation features come from: the stored pyramid, or fmap1 + the pooled fmap2 pyramid (on demand).
+struct LookupSource {
+    const float *pyr;
+    const int64_t *level_offsets;
+    const float *fmap1, *fmap2_pyr;
+    int C;
+};
 // Optional three-stream schedule of one loop iteration (raft_iterate_basic_overlap_f32):
 //   main  lookup, convc1, convc2, [join flow branch] conv, GRU, [join previous upsample] fh1_mask0, fh2
 //   s1    convf1, convf2                 (needs only the previous iteration's flow)
@@ -575,8 +582,16 @@ struct Overlap {
 
 // with_mask = false (final-only prediction, every iteration but the last): the mask branch -- mask.0 (the second half of
 // fh1_mask0) and mask.2 -- is skipped; flow_head.conv1 alone runs from wts->fh1_w.
+// The loops run the lookup fused into convc1 (raft_lookup_convc1_f32) when they read a stored volume, the repacked
+// kernel was supplied and RAFT_LOOKUP_FUSED is not switched off.
+static bool lookup_is_fused(const raft_basic_update_weights *wts, const LookupSource *src) {
+    return src && src->pyr && wts->convc1_f.wp != nullptr && raft_opt(RAFT_OPT_LOOKUP_FUSED, 1) != 0;
+}
+
+// fused_src != NULL: st->corr is NOT read; cor1 comes from the volume through the fused kernel
 static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h, int w, const raft_state *st,
-                             void *stream, StageTimer *tm, Overlap *ov = nullptr, bool with_mask = true) {
+                             void *stream, StageTimer *tm, Overlap *ov = nullptr, bool with_mask = true,
+                             const LookupSource *fused_src = nullptr) {
     RAFT_REQUIRE_PTR(wts);
     RAFT_TRY(check_state(st));
     RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
@@ -589,7 +604,11 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     float *zb = ws + M * WS_Z, *rh = ws + M * WS_RH, *fm = ws + M * WS_FM;
 
     // ---- BasicMotionEncoder (update.py:97-106)
-    {   // cor = relu(convc1(corr))            1x1, 324(+28 zero pad) -> 256
+    if (fused_src) {   // cor = relu(convc1(retrieve(coords1)))   lookup + 1x1, 324 -> 256, one kernel
+        RAFT_TRY(raft_lookup_convc1_f32(fused_src->pyr, fused_src->level_offsets, st->coords1, B, h, w, wts->convc1_f.wp,
+                                        wts->convc1_f.bias, wts->convc1_f.npad, 256, cor1, 256, stream));
+        RAFT_MARK();
+    } else {   // cor = relu(convc1(corr))            1x1, 324(+28 zero pad) -> 256
         ConvArgs a = conv_args(wts->convc1, st->corr, CORR_LD, CORR_LD, nullptr, 0, 0, B, h, w, 256, cor1, 256);
         RAFT_TRY(raft_launch_conv(a, 1, 1, EPI_RELU, s));
         RAFT_MARK();
@@ -689,21 +708,16 @@ extern "C" int raft_iterate_basic_f32(const raft_basic_update_weights *wts, cons
     RAFT_TRY(check_state(st));
     RAFT_REQUIRE(B > 0 && h > 0 && w > 0 && iters > 0, RAFT_E_SHAPE);
     const int64_t up = (int64_t)B * 64 * h * w * 2;
+    const LookupSource src = {pyr, level_offsets, nullptr, nullptr, 0};
+    const bool fused = lookup_is_fused(wts, &src);
     for (int i = 0; i < iters; ++i) {
-        RAFT_TRY(raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream));
-        RAFT_TRY(update_basic_impl(wts, B, h, w, st, stream, nullptr));
+        if (!fused) RAFT_TRY(raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream));
+        RAFT_TRY(update_basic_impl(wts, B, h, w, st, stream, nullptr, nullptr, true, fused ? &src : nullptr));
         RAFT_TRY(raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream));
     }
     return RAFT_OK;
 }
 
-// Where the loop's correlation features come from: the stored pyramid, or fmap1 + the pooled fmap2 pyramid (on demand).
-struct LookupSource {
-    const float *pyr;
-    const int64_t *level_offsets;
-    const float *fmap1, *fmap2_pyr;
-    int C;
-};
 static int loop_lookup(const LookupSource &src, const raft_state *st, int B, int h, int w, void *stream) {
     if (src.pyr) return raft_corr_lookup_f32(src.pyr, src.level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream);
     return raft_corr_lookup_ondemand_f32(src.fmap1, src.fmap2_pyr, st->coords1, B, h, w, src.C, 4, 4, st->corr, CORR_LD, stream);
@@ -818,8 +832,9 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
     int rc = (int)hipEventRecord(ov.e_fh, s);   // state prepared on `stream`: the flow branch may start
     for (int i = 0; i < iters && rc == RAFT_OK; ++i) {
         const bool with_mask = !final_only || i == iters - 1;
-        rc = loop_lookup(src, st, B, h, w, stream);
-        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov, with_mask);
+        const bool fused = lookup_is_fused(wts, &src);
+        rc = fused ? RAFT_OK : loop_lookup(src, st, B, h, w, stream);
+        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov, with_mask, fused ? &src : nullptr);
         if (!with_mask) continue;
         // upsample on the mask branch: needs mask2 (same stream) and the flow written by fh2
         if (rc == RAFT_OK) rc = (int)hipStreamWaitEvent(ov.s2, ov.e_fh, 0);
@@ -945,11 +960,14 @@ extern "C" int raft_iterate_basic_timed_f32(const raft_basic_update_weights *wts
     StageTimer tm = {ev, 0, nev};
     const int64_t up = (int64_t)B * 64 * h * w * 2;
     int rc = RAFT_OK;
+    const LookupSource src = {pyr, level_offsets, nullptr, nullptr, 0};
+    const bool fused = lookup_is_fused(wts, &src);
     tm.mark(s);
     for (int i = 0; i < iters && rc == RAFT_OK; ++i) {
-        rc = raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream);
+        // RAFT_LOOKUP_FUSED as in the product loops: fused, the lookup stage is empty and the convc1 stage is the fused kernel
+        if (!fused) rc = raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream);
         tm.mark(s);
-        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, &tm);
+        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, &tm, nullptr, true, fused ? &src : nullptr);
         if (rc == RAFT_OK) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream);
         tm.mark(s);
     }

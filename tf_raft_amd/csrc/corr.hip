@@ -518,6 +518,164 @@ extern "C" int raft_corr_lookup_f32(const float *pyr, const int64_t *level_offse
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lookup fused into the first convolution of the motion encoder:
+//   cor1 = relu(convc1(CorrBlock.retrieve(coords1)))        [reference corr.py:116-152 + update.py:91, 98]
+// The (B, h, w, 324) lookup output never exists in HBM: a workgroup owns 28 queries (56 x 64 = 128 x 28: the feature maps
+// of 448 x 512 frames cut into 512 x B / 4 equal workgroups, two per CU at B = 4 with no ragged last round), runs the
+// strip lookup of corr_lookup_strip_kernel for them in four rounds of seven queries -- the SAME device functions, so the
+// window values are bit-identical to raft_corr_lookup_f32 -- and leaves the values as rows of an LDS tile
+// [32 queries][4 levels x 84]: K order = level-major, each level's 81 channels padded to 84 (the weights are packed to
+// match, tf_raft_amd/packing.py pack_convc1_fused; rows 28..31 and the pad columns are zero).  The tile is then the A
+// operand of a [32 x 336] . [336 x 256] fp32-MFMA product (16x16x4; wave w owns channels 64 w .. 64 w + 63: 2 row blocks x
+// 4 column blocks; weight fragments straight from L2, one 16-channel block ahead), bias + relu in the epilogue.
+// The gathers of round r + 1 are issued before round r is evaluated; with two workgroups per CU one workgroup's MFMA
+// phase runs under the other's lookup phase.  Versus lookup + convc1 as two kernels this removes the 18.6 MB (B = 4)
+// write and re-read of the lookup output and one kernel boundary per iteration.
+// ------------------------------------------------------------------------------------------------
+struct FusedLookupArgs {
+    LookupArgs lk;          // lk.out / lk.ld_out unused
+    const float *wp;        // [84 k-quads][npad][4]
+    const float *bias;      // [npad]
+    float *out;             // (nq, ldo): cor1
+    int ldo, npad, nvalid;
+};
+
+constexpr int FL_ROUNDS = 4, FL_LVLK = 84, FL_K = 4 * FL_LVLK, FL_LDA = FL_K + 4, FL_ROWS = 32;
+
+template <int R>
+__global__ void __launch_bounds__(256, 2) lookup_convc1_kernel(FusedLookupArgs p) {
+    using G = StripCfg<R>;
+    constexpr int L = G::L, D = G::D, FP = G::FP, SP = G::SP, QB = G::QB, NR = G::NR;
+    static_assert(R == 4 && QB == 7 && D * D <= FL_LVLK, "28 queries per workgroup, 81 channels per level padded to 84");
+    constexpr int QW = QB * FL_ROUNDS;                                   // 28 queries per workgroup
+    __shared__ __attribute__((aligned(16))) float sA[FL_ROWS * FL_LDA];
+    __shared__ __attribute__((aligned(16))) float sfp[QB * L * FP];
+    __shared__ __attribute__((aligned(16))) int sty[QB * SP][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ql = tid / SP, j = tid - ql * SP;
+    const int l = j / D, a = j - l * D;
+    const int64_t qbase = (int64_t)blockIdx.x * QW;
+
+    for (int i = tid; i < FL_ROWS * FL_LDA / 4; i += 256) ((f32x4 *)sA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- phase A: four rounds of the strip lookup
+    float v[L][NR];
+    int org[L][2];
+    float2 cq;
+    auto issue = [&](int rd) {
+        const int64_t q0 = qbase + rd * QB;
+        const int64_t left = p.lk.nq - q0;
+        const int nq_here = (int)(left < QB ? (left < 1 ? 1 : left) : QB);      // >= 1: loads stay in range
+        const int64_t q0c = left < 1 ? p.lk.nq - 1 : q0;                        // a round past the end re-reads the last query
+        const int qc = ql < nq_here ? ql : nq_here - 1;
+        cq = *(const float2 *)(p.lk.coords + 2 * (q0c + qc));
+        strip_gather<R>(p.lk, q0c, qc, cq, j, v, org);
+    };
+    issue(0);
+    for (int rd = 0; rd < FL_ROUNDS; ++rd) {
+        const int64_t q0 = qbase + rd * QB;
+        const int64_t left = p.lk.nq - q0;
+        const int nq_here = (int)(left < 0 ? 0 : (left < QB ? left : QB));
+        const bool active = ql < nq_here;
+        int4 tx, ty;
+        strip_taps<R>(p.lk, cq, l, a, org, tx, ty);
+        if (active) *(int4 *)sty[tid] = ty;
+#pragma unroll
+        for (int k = 0; k < L; ++k)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int s = j + SP * r;
+                if (s < FP && active) sfp[(ql * L + k) * FP + s] = v[k][r];
+            }
+        __syncthreads();
+        if (rd + 1 < FL_ROUNDS) issue(rd + 1);                             // next round's gathers fly under this round's strips
+        if (active) {
+            float o[D];
+            strip_eval<R>(sfp + (ql * L + l) * FP, sty + ql * SP + l * D, tx, o);
+            float *dst = sA + (rd * QB + ql) * FL_LDA + l * FL_LVLK + a * D;
+#pragma unroll
+            for (int b = 0; b < D; ++b) dst[b] = o[b];
+        }
+        __syncthreads();                                                   // strips read; footprints may be overwritten
+    }
+
+    // ---- phase B: cor1 tile = relu(A . W + bias)
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int n0 = wv * 64;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 *wq = (const f32x4 *)p.wp + (int64_t)g4 * p.npad + n0 + r16;      // k-quad 4 blk + g4, column n0 + 16 cb + r16
+    f32x4 fb[2][4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) fb[0][cb] = wq[cb * 16];
+    constexpr int NBLK = FL_K / 16;                                         // 21 blocks of 16 channels
+#pragma unroll 3
+    for (int blk = 0; blk < NBLK; ++blk) {
+        const int cur = blk & 1;
+        if (blk + 1 < NBLK) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) fb[cur ^ 1][cb] = wq[(int64_t)(blk + 1) * 4 * p.npad + cb * 16];
+        }
+        f32x4 fa[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) fa[rb] = *(const f32x4 *)(sA + (rb * 16 + r16) * FL_LDA + blk * 16 + g4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[rb][e], fb[cur][cb][e], acc[rb][cb], 0, 0, 0);
+    }
+    // D[row = query 16 rb + 4 g4 + e][col = channel n0 + 16 cb + r16]
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int n = n0 + cb * 16 + r16;
+        const float bias = p.bias[n];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = rb * 16 + g4 * 4 + e;
+                const int64_t q = qbase + row;
+                if (row < QW && q < p.lk.nq && n < p.nvalid) p.out[q * p.ldo + n] = fmaxf(acc[rb][cb][e] + bias, 0.f);
+            }
+    }
+}
+
+extern "C" int raft_lookup_convc1_f32(const float *pyr, const int64_t *level_offsets, const float *coords, int B, int h, int w,
+                                      const float *wp, const float *bias, int npad, int nvalid, float *out, int ldo,
+                                      void *stream) {
+    RAFT_REQUIRE_PTR(pyr);
+    RAFT_REQUIRE_PTR(level_offsets);
+    RAFT_REQUIRE_PTR(coords);
+    RAFT_REQUIRE_PTR(wp);
+    RAFT_REQUIRE_PTR(bias);
+    RAFT_REQUIRE_PTR(out);
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
+    RAFT_REQUIRE(npad == 256 && nvalid > 0 && nvalid <= npad && ldo >= nvalid, RAFT_E_UNSUPPORTED);
+    RAFT_REQUIRE(raft_aligned16(wp), RAFT_E_ALIGN);
+    FusedLookupArgs a;
+    RAFT_TRY(raft_make_geom(h, w, 4, level_offsets, &a.lk.g));
+    a.lk.pyr = pyr;
+    a.lk.coords = coords;
+    a.lk.out = nullptr;
+    a.lk.nq = (int64_t)B * h * w;
+    a.lk.ld_out = 0;
+    a.wp = wp;
+    a.bias = bias;
+    a.out = out;
+    a.ldo = ldo;
+    a.npad = npad;
+    a.nvalid = nvalid;
+    lookup_convc1_kernel<4><<<raft_ceil_div(a.lk.nq, 28), 256, 0, (hipStream_t)stream>>>(a);
+    return raft_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // standalone bilinear_sampler and coords_grid
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bilinear_sampler_kernel(const float *__restrict__ image,

@@ -140,6 +140,21 @@ def fuse_n(weights: Dict[str, np.ndarray], names: Sequence[str]):
     return k, b
 
 
+def pack_convc1_fused(kernel: np.ndarray, bias: np.ndarray, levels: int = 4, radius: int = 4):
+    """convc1 (1, 1, levels*(2r+1)^2, 256) for ``raft_lookup_convc1_f32``: K reordered level-major with each level's
+    (2r+1)^2 = 81 rows padded to 84 (zero rows), packed as k-quads: (levels * 21, 256, 4)."""
+    k = np.asarray(kernel, dtype=np.float32)
+    d2 = (2 * radius + 1) ** 2
+    if k.shape[:3] != (1, 1, levels * d2) or k.shape[3] != 256 or radius != 4 or levels != 4:
+        raise ValueError(f'pack_convc1_fused expects a (1, 1, 324, 256) kernel, got {k.shape}')
+    lvl = 84
+    full = np.zeros((levels * lvl, 256), dtype=np.float32)
+    for l in range(levels):
+        full[l * lvl:l * lvl + d2] = k[0, 0, l * d2:(l + 1) * d2]
+    wp = full.reshape(levels * lvl // 4, 4, 256).transpose(0, 2, 1)
+    return np.ascontiguousarray(wp), np.asarray(bias, dtype=np.float32).copy(), 256
+
+
 def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_block') -> List[Tuple[str, np.ndarray, np.ndarray, int]]:
     """[(field, packed_kernel, bias, npad)] for ``raft_basic_update_weights``
     (reference update.py:128-153; GRU input order hx = [h | inp | motion(126) | flow(2)])."""
@@ -203,6 +218,8 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     # F(4, 5)-transformed copies of the SepConvGRU convolutions
     order4 = ['gru_zr1_w4', 'gru_q1_w4', 'gru_zr2_w4', 'gru_q2_w4']
     out = out + sorted(gru_w4, key=lambda e: order4.index(e[0]))
+    wp, bb, npad = pack_convc1_fused(w[f'{p}/encoder/convc1/kernel'], w[f'{p}/encoder/convc1/bias'])
+    out.append(('convc1_f', wp, bb, npad))
     return out
 
 
