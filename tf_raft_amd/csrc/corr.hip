@@ -522,14 +522,14 @@ extern "C" int raft_corr_lookup_f32(const float *pyr, const int64_t *level_offse
 //   cor1 = relu(convc1(CorrBlock.retrieve(coords1)))        [reference corr.py:116-152 + update.py:91, 98]
 // The (B, h, w, 324) lookup output never exists in HBM: a workgroup owns 28 queries (56 x 64 = 128 x 28: the feature maps
 // of 448 x 512 frames cut into 512 x B / 4 equal workgroups, two per CU at B = 4 with no ragged last round), runs the
-// strip lookup of corr_lookup_strip_kernel for them in four rounds of seven queries -- the SAME device functions, so the
+// strip lookup of corr_lookup_strip_kernel for them in two rounds of fourteen queries -- the SAME device functions, so the
 // window values are bit-identical to raft_corr_lookup_f32 -- and leaves the values as rows of an LDS tile
 // [32 queries][4 levels x 84]: K order = level-major, each level's 81 channels padded to 84 (the weights are packed to
 // match, tf_raft_amd/packing.py pack_convc1_fused; rows 28..31 and the pad columns are zero).  The tile is then the A
-// operand of a [32 x 336] . [336 x 256] fp32-MFMA product (16x16x4; wave w owns channels 64 w .. 64 w + 63: 2 row blocks x
-// 4 column blocks; weight fragments straight from L2, one 16-channel block ahead), bias + relu in the epilogue.
-// The gathers of round r + 1 are issued before round r is evaluated; with two workgroups per CU one workgroup's MFMA
-// phase runs under the other's lookup phase.  Versus lookup + convc1 as two kernels this removes the 18.6 MB (B = 4)
+// operand of a [32 x 336] . [336 x 256] fp32-MFMA product (16x16x4; 512 threads, wave w owns channels 32 w .. 32 w + 31:
+// 2 row blocks x 2 column blocks; weight fragments straight from L2, two 16-channel blocks ahead), bias + relu in the
+// epilogue.  The gathers of BOTH rounds are issued before anything else (one exposed round trip per workgroup); with two
+// workgroups = 16 waves per CU one workgroup's MFMA phase runs under the other's lookup phase.  Versus lookup + convc1 as two kernels this removes the 18.6 MB (B = 4)
 // write and re-read of the lookup output and one kernel boundary per iteration.
 // ------------------------------------------------------------------------------------------------
 struct FusedLookupArgs {
@@ -540,84 +540,85 @@ struct FusedLookupArgs {
     int ldo, npad, nvalid;
 };
 
-constexpr int FL_ROUNDS = 4, FL_LVLK = 84, FL_K = 4 * FL_LVLK, FL_LDA = FL_K + 4, FL_ROWS = 32;
+constexpr int FL_ROUNDS = 2, FL_QB = 14, FL_THREADS = 512, FL_LVLK = 84, FL_K = 4 * FL_LVLK, FL_LDA = FL_K + 4, FL_ROWS = 32;
 
 template <int R>
-__global__ void __launch_bounds__(256, 2) lookup_convc1_kernel(FusedLookupArgs p) {
+__global__ void __launch_bounds__(FL_THREADS, 1) lookup_convc1_kernel(FusedLookupArgs p) {
     using G = StripCfg<R>;
-    constexpr int L = G::L, D = G::D, FP = G::FP, SP = G::SP, QB = G::QB, NR = G::NR;
-    static_assert(R == 4 && QB == 7 && D * D <= FL_LVLK, "28 queries per workgroup, 81 channels per level padded to 84");
-    constexpr int QW = QB * FL_ROUNDS;                                   // 28 queries per workgroup
+    constexpr int L = G::L, D = G::D, FP = G::FP, SP = G::SP, NR = G::NR;
+    static_assert(R == 4 && FL_QB * SP <= FL_THREADS && D * D <= FL_LVLK, "14 queries per round, 81 channels per level padded to 84");
+    constexpr int QW = FL_QB * FL_ROUNDS;                                // 28 queries per workgroup
     __shared__ __attribute__((aligned(16))) float sA[FL_ROWS * FL_LDA];
-    __shared__ __attribute__((aligned(16))) float sfp[QB * L * FP];
-    __shared__ __attribute__((aligned(16))) int sty[QB * SP][4];
+    __shared__ __attribute__((aligned(16))) float sfp[FL_QB * L * FP];
+    __shared__ __attribute__((aligned(16))) int sty[FL_QB * SP][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ql = tid / SP, j = tid - ql * SP;
+    const int ql = min(tid / SP, FL_QB - 1), j = tid - (tid / SP) * SP;  // threads 504..511 shadow query 13 (never stored)
+    const bool lk_thread = tid < FL_QB * SP;
     const int l = j / D, a = j - l * D;
     const int64_t qbase = (int64_t)blockIdx.x * QW;
 
-    for (int i = tid; i < FL_ROWS * FL_LDA / 4; i += 256) ((f32x4 *)sA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- phase A: four rounds of the strip lookup
-    float v[L][NR];
-    int org[L][2];
-    float2 cq;
-    auto issue = [&](int rd) {
-        const int64_t q0 = qbase + rd * QB;
-        const int64_t left = p.lk.nq - q0;
-        const int nq_here = (int)(left < QB ? (left < 1 ? 1 : left) : QB);      // >= 1: loads stay in range
-        const int64_t q0c = left < 1 ? p.lk.nq - 1 : q0;                        // a round past the end re-reads the last query
-        const int qc = ql < nq_here ? ql : nq_here - 1;
-        cq = *(const float2 *)(p.lk.coords + 2 * (q0c + qc));
-        strip_gather<R>(p.lk, q0c, qc, cq, j, v, org);
-    };
-    issue(0);
+    // ---- phase A: the strip lookup, two rounds of fourteen queries; the gathers of BOTH rounds are issued up front
+    float v[FL_ROUNDS][L][NR];
+    int org[FL_ROUNDS][L][2];
+    float2 cq[FL_ROUNDS];
+#pragma unroll
     for (int rd = 0; rd < FL_ROUNDS; ++rd) {
-        const int64_t q0 = qbase + rd * QB;
+        const int64_t q0 = qbase + rd * FL_QB;
         const int64_t left = p.lk.nq - q0;
-        const int nq_here = (int)(left < 0 ? 0 : (left < QB ? left : QB));
-        const bool active = ql < nq_here;
+        const int nq_here = (int)(left < FL_QB ? (left < 1 ? 1 : left) : FL_QB);   // >= 1: loads stay in range
+        const int64_t q0c = left < 1 ? p.lk.nq - 1 : q0;                           // a round past the end re-reads the last query
+        const int qc = ql < nq_here ? ql : nq_here - 1;
+        cq[rd] = *(const float2 *)(p.lk.coords + 2 * (q0c + qc));
+        strip_gather<R>(p.lk, q0c, qc, cq[rd], j, v[rd], org[rd]);
+    }
+    for (int i = tid; i < FL_ROWS * FL_LDA / 4; i += FL_THREADS) ((f32x4 *)sA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rd = 0; rd < FL_ROUNDS; ++rd) {
+        const int64_t left = p.lk.nq - (qbase + rd * FL_QB);
+        const int nq_here = (int)(left < 0 ? 0 : (left < FL_QB ? left : FL_QB));
+        const bool active = lk_thread && ql < nq_here;
         int4 tx, ty;
-        strip_taps<R>(p.lk, cq, l, a, org, tx, ty);
-        if (active) *(int4 *)sty[tid] = ty;
+        strip_taps<R>(p.lk, cq[rd], l, a, org[rd], tx, ty);
+        if (rd) __syncthreads();                                           // the previous round's strips have been read
+        if (active) *(int4 *)sty[ql * SP + j] = ty;
 #pragma unroll
         for (int k = 0; k < L; ++k)
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int s = j + SP * r;
-                if (s < FP && active) sfp[(ql * L + k) * FP + s] = v[k][r];
+                if (s < FP && active) sfp[(ql * L + k) * FP + s] = v[rd][k][r];
             }
         __syncthreads();
-        if (rd + 1 < FL_ROUNDS) issue(rd + 1);                             // next round's gathers fly under this round's strips
         if (active) {
             float o[D];
             strip_eval<R>(sfp + (ql * L + l) * FP, sty + ql * SP + l * D, tx, o);
-            float *dst = sA + (rd * QB + ql) * FL_LDA + l * FL_LVLK + a * D;
+            float *dst = sA + (rd * FL_QB + ql) * FL_LDA + l * FL_LVLK + a * D;
 #pragma unroll
             for (int b = 0; b < D; ++b) dst[b] = o[b];
         }
-        __syncthreads();                                                   // strips read; footprints may be overwritten
     }
+    __syncthreads();
 
-    // ---- phase B: cor1 tile = relu(A . W + bias)
+    // ---- phase B: cor1 tile = relu(A . W + bias); wave wv owns channels 32 wv .. 32 wv + 31 (2 row x 2 column blocks)
     const int r16 = lane & 15, g4 = lane >> 4;
-    const int n0 = wv * 64;
-    f32x4 acc[2][4];
+    const int n0 = wv * 32;
+    f32x4 acc[2][2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 *wq = (const f32x4 *)p.wp + (int64_t)g4 * p.npad + n0 + r16;      // k-quad 4 blk + g4, column n0 + 16 cb + r16
-    f32x4 fb[2][4];
+    constexpr int NBLK = FL_K / 16, PF = 3;                                 // 21 blocks of 16 channels; fragments PF blocks ahead
+    f32x4 fb[PF][2];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) fb[0][cb] = wq[cb * 16];
-    constexpr int NBLK = FL_K / 16;                                         // 21 blocks of 16 channels
-#pragma unroll 3
+    for (int u = 0; u < PF - 1; ++u)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) fb[u][cb] = wq[(int64_t)u * 4 * p.npad + cb * 16];
+#pragma unroll
     for (int blk = 0; blk < NBLK; ++blk) {
-        const int cur = blk & 1;
-        if (blk + 1 < NBLK) {
+        if (blk + PF - 1 < NBLK) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) fb[cur ^ 1][cb] = wq[(int64_t)(blk + 1) * 4 * p.npad + cb * 16];
+            for (int cb = 0; cb < 2; ++cb) fb[(blk + PF - 1) % PF][cb] = wq[(int64_t)(blk + PF - 1) * 4 * p.npad + cb * 16];
         }
         f32x4 fa[2];
 #pragma unroll
@@ -627,12 +628,12 @@ __global__ void __launch_bounds__(256, 2) lookup_convc1_kernel(FusedLookupArgs p
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[rb][e], fb[cur][cb][e], acc[rb][cb], 0, 0, 0);
+                for (int cb = 0; cb < 2; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[rb][e], fb[blk % PF][cb][e], acc[rb][cb], 0, 0, 0);
     }
     // D[row = query 16 rb + 4 g4 + e][col = channel n0 + 16 cb + r16]
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < 2; ++cb) {
         const int n = n0 + cb * 16 + r16;
         const float bias = p.bias[n];
 #pragma unroll
@@ -671,7 +672,7 @@ extern "C" int raft_lookup_convc1_f32(const float *pyr, const int64_t *level_off
     a.ldo = ldo;
     a.npad = npad;
     a.nvalid = nvalid;
-    lookup_convc1_kernel<4><<<raft_ceil_div(a.lk.nq, 28), 256, 0, (hipStream_t)stream>>>(a);
+    lookup_convc1_kernel<4><<<raft_ceil_div(a.lk.nq, FL_QB * FL_ROUNDS), FL_THREADS, 0, (hipStream_t)stream>>>(a);
     return raft_launch_status();
 }
 

@@ -1,6 +1,7 @@
 """Workload of the PMC passes (tools/pmc_traffic.sh): ONE full forward (encoders, volume build, state preparation) and
-then the SINGLE-STREAM prediction loop, `iters` iterations, at batch B -- launch order inside an iteration is fixed
-(bench.py STAGES), which is how tools/pmc_traffic.py attributes dispatches to stages.
+then the SINGLE-STREAM prediction loop, `iters` iterations, at batch B -- first with the product default (lookup fused into
+convc1: that kernel is attributed by name), then with RAFT_LOOKUP_FUSED=0, where the launch order inside an iteration is
+fixed (bench.py STAGES), which is how tools/pmc_traffic.py attributes those dispatches to stages.
 usage: python tools/pmc_loop.py <batch> <iters>"""
 import os
 import sys
@@ -17,7 +18,11 @@ gen = torch.Generator(device=dev)
 gen.manual_seed(1000)
 i1 = torch.rand((B, 448, 512, 3), device=dev, generator=gen) * 255.0
 i2 = torch.rand((B, 448, 512, 3), device=dev, generator=gen) * 255.0
+from tf_raft_amd import _ffi  # noqa: E402
 model = tf_raft_amd.RAFT(iters_pred=iters, overlap=False)
+out = model([i1, i2])                            # product default: lookup fused into convc1 (attributed by kernel name)
+torch.cuda.synchronize()
+_ffi.set_option('RAFT_LOOKUP_FUSED', 0)          # then the two-kernel loop: 14 kernels per iteration, attributed by order
 out = model([i1, i2])
 torch.cuda.synchronize()
 print('done', float(out[-1].abs().max()))

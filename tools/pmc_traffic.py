@@ -29,6 +29,7 @@ def algorithmic_bytes_per_pair(h=56, w=64):
         'gru_q1': M * (256 + 128 + 128 + 128 + 128) * f, 'gru_q2': M * (256 + 128 + 128 + 128 + 128) * f,
         'fh1_mask0': M * (128 + 512) * f, 'fh2': M * (256 + 6) * f, 'mask2': M * (256 + 576) * f,
         'corr_build': 2 * M * 256 * f + sum((h >> l) * (w >> l) for l in range(4)) * M * f,
+        'lookup_convc1_fused': M * (4 * 100 * f + 8 + 256 * f),      # footprints + coords in, cor1 out
     }
 
 
@@ -54,6 +55,8 @@ def attribute(rows):
             out['corr_build'].append(v)
         elif 'fmap_' in name:
             out['corr_build_fmap_pyramid'].append(v)
+        elif 'lookup_convc1' in name:
+            out['lookup_convc1_fused'].append(v)
     loop = rows[first:]
     last = max(i for i, r in enumerate(loop) if 'upsample_convex' in r[1])     # torch reductions of the caller follow
     loop = loop[:last + 1]
@@ -79,13 +82,13 @@ def main():
                        '2 * FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md HBM: gfx950 tallies 128-byte read requests at '
                        '64 bytes). Regenerate with: bash tools/pmc_traffic.sh <tag> 8'}
     rows = []
-    for st in STAGES + ['corr_build', 'corr_build_fmap_pyramid']:
+    for st in STAGES + ['lookup_convc1_fused', 'corr_build', 'corr_build_fmap_pyramid']:
         if st not in fetch or st not in write:
             continue
         f = sum(fetch[st]) / len(fetch[st])
         wv = sum(write[st]) / len(write[st])
         hbm = (2 * f + wv) * 1024
-        res[st] = {'batch': batch, 'in_loop': st in STAGES, 'fetch_size_kib_raw': round(f, 1), 'write_size_kib': round(wv, 1),
+        res[st] = {'batch': batch, 'in_loop': st in STAGES or st == 'lookup_convc1_fused', 'fetch_size_kib_raw': round(f, 1), 'write_size_kib': round(wv, 1),
                    'hbm_bytes_per_launch': int(round(hbm)), 'launches_averaged': len(fetch[st]),
                    'algorithmic_bytes_per_pair': alg.get(st),
                    'algorithmic_bytes_per_launch': alg[st] * batch if st in alg else None,
