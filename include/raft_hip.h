@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 202          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 203          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -445,6 +445,33 @@ int raft_relu_backward_f32(const float *y, const float *dy, float *dx, int64_t n
 int64_t raft_conv2d_wgrad_workspace_floats(int cin, int cout, int B, int H, int W, int kh, int kw);
 int raft_conv2d_wgrad_f32(const float *x, int ldx, int cin, const float *dy, int ldy, int cout, int B, int H, int W,
                           int kh, int kw, float *d_kernel, float *d_bias, float *workspace, void *stream);
+
+/* ---- second slice: everything one BasicUpdateBlock call needs (tf_raft_amd/grad.py basic_update_block_backward) */
+
+/* relu(Conv2D(7, 7, Cin = 2 -> cout)) of the flow (update.py:93, 76): kernel (98, cout) = Keras (7,7,2,cout) flattened,
+ * cout in {64, 128}; out (B, H, W, ldo).  The inference loop runs this kernel inside raft_update_*_f32. */
+int raft_conv7x7_c2_f32(const float *flow, const float *kernel, const float *bias, int cout, int B, int H, int W,
+                        float *out, int ldo, void *stream);
+/* Its backward for an upstream gradient dy that already carries the relu mask: d_flow (B, H, W, 2), d_kernel (98, cout),
+ * d_bias (cout).  Deterministic; workspace raft_conv7x7_c2_wgrad_workspace_floats(cout) floats. */
+int64_t raft_conv7x7_c2_wgrad_workspace_floats(int cout);
+int raft_conv7x7_c2_backward_f32(const float *flow, const float *dy, int ldy, const float *kernel, int cout, int B, int H,
+                                 int W, float *d_flow, float *d_kernel, float *d_bias, float *workspace, void *stream);
+
+/* SepConvGRU gates (update.py:51-67) as separate kernels, so that the training forward keeps z, r, q:
+ *   zr: a_zr (M, 2C) = [convz | convr] pre-activations -> z = sigmoid, r = sigmoid, rh = r * h        (all (M, C))
+ *   q : a_q (n) -> q = tanh(a_q), h_new = (1 - z) h + z q
+ * and their backward:
+ *   q_backward: d_h_new -> dz_pre = d (q - h) z (1 - z), dq_pre = d z (1 - q^2), dh = d (1 - z)      (dh overwritten)
+ *   r_backward: d_rh -> dr_pre = d h r (1 - r), dh += d r                                           (dh accumulated) */
+int raft_gru_gate_zr_f32(const float *a_zr, const float *h, int C, int64_t M, float *z, float *r, float *rh, void *stream);
+int raft_gru_gate_q_f32(const float *a_q, const float *z, const float *h, int64_t n, float *q, float *h_new, void *stream);
+int raft_gru_gate_q_backward_f32(const float *d_h_new, const float *z, const float *q, const float *h, int64_t n,
+                                 float *dz_pre, float *dq_pre, float *dh, void *stream);
+int raft_gru_gate_r_backward_f32(const float *d_rh, const float *r, const float *h, int64_t n, float *dr_pre, float *dh,
+                                 void *stream);
+/* out = alpha * a + beta * b (b may be NULL): gradient accumulation where two branches meet, the 0.25 of the mask head. */
+int raft_axpby_f32(float alpha, const float *a, float beta, const float *b, float *out, int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

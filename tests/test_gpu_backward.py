@@ -145,3 +145,53 @@ def test_backward_argument_checks():
     assert lib.raft_conv2d_wgrad_workspace_floats(0, 4, 1, 4, 4, 3, 3) == 0
     assert lib.raft_relu_backward_f32(None, None, None, 4, None) == -1
     assert lib.raft_sequence_loss_grad_f32(None, None, None, 8, 1, 4, 0.8, 400.0, 1.0, None, None) == -1
+
+
+@pytest.mark.parametrize('shape', [(1, 16, 24), (2, 9, 13)])
+def test_basic_update_block_backward_matches_autograd(rng, shape):
+    """Second slice: one whole BasicUpdateBlock call (reference update.py:128-153: motion encoder, SepConvGRU, flow head,
+    mask head) -- forward in training form against the float64 oracle, then the backward of all three outputs against
+    torch autograd through ``oracle.layers.basic_update_block``: gradients w.r.t. the four inputs and all 30 kernels and
+    biases."""
+    from oracle.layers import W, basic_update_block
+    from tf_raft_amd import grad
+    from tf_raft_amd import weights as wm
+    B, h, w = shape
+    wts = {k: v for k, v in wm.init_weights('raft', seed=7, perturb=True).items() if k.startswith('update_block')}
+    net = np.tanh(rng.normal(size=(B, h, w, 128))).astype(np.float32)
+    inp = np.maximum(rng.normal(size=(B, h, w, 128)), 0).astype(np.float32)
+    corr = rng.normal(size=(B, h, w, 324)).astype(np.float32)
+    flow = (rng.normal(size=(B, h, w, 2)) * 2).astype(np.float32)
+    ow = W(wts, torch.float64)
+    for t in ow.t.values():
+        t.requires_grad_(True)
+    tin = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (net, inp, corr, flow)]
+    rn, rm, rd = basic_update_block(ow, 'update_block', *tin)
+    gn, gm, gd, saved = grad.basic_update_block_forward(wts, net, inp, corr, flow)
+    for name, got, want in (('net', gn, rn), ('mask', gm, rm), ('delta', gd, rd)):
+        err = float(np.abs(_np(got) - want.detach().numpy()).max())
+        report(f'update block training forward {shape} {name}', max_abs_vs_f64=err)
+        assert err <= 5e-5
+    d_net = rng.normal(size=rn.shape).astype(np.float32)
+    d_mask = (rng.normal(size=rm.shape) * 0.1).astype(np.float32)
+    d_delta = rng.normal(size=rd.shape).astype(np.float32)
+    torch.autograd.backward([rn, rm, rd], [torch.tensor(a, dtype=torch.float64) for a in (d_net, d_mask, d_delta)])
+    din, dw = grad.basic_update_block_backward(wts, saved, d_net, d_mask, d_delta)
+    worst = 0.0
+    for name, t in zip(('net', 'inp', 'corr', 'flow'), tin):
+        want = t.grad.numpy()
+        rel = float(np.abs(_np(din[name]) - want).max() / max(1.0, np.abs(want).max()))
+        report(f'update block backward {shape} d_{name}', rel_err=rel, scale=float(np.abs(want).max()))
+        worst = max(worst, rel)
+        assert _np(din[name]).shape == want.shape
+    assert len(dw) == 30
+    for name, got in sorted(dw.items()):
+        want = ow.t[name].grad.numpy()
+        assert _np(got).shape == want.shape, name
+        rel = float(np.abs(_np(got) - want).max() / max(1.0, np.abs(want).max()))
+        worst = max(worst, rel)
+        if rel > 1e-5:
+            report(f'update block backward {shape} {name}', rel_err=rel, scale=float(np.abs(want).max()))
+        assert rel <= 5e-5, (name, rel)
+    report(f'update block backward {shape}', worst_rel_err_over_34_gradients=worst)
+    assert worst <= 5e-5

@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 202     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 203     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -82,6 +82,14 @@ _SIGNATURES = {
     'raft_relu_backward_f32': (_I, [_P, _P, _P, C.c_int64, _P]),
     'raft_conv2d_wgrad_workspace_floats': (C.c_int64, [_I, _I, _I, _I, _I, _I, _I]),
     'raft_conv2d_wgrad_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'raft_conv7x7_c2_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    'raft_conv7x7_c2_wgrad_workspace_floats': (C.c_int64, [_I]),
+    'raft_conv7x7_c2_backward_f32': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'raft_gru_gate_zr_f32': (_I, [_P, _P, _I, C.c_int64, _P, _P, _P, _P]),
+    'raft_gru_gate_q_f32': (_I, [_P, _P, _P, C.c_int64, _P, _P, _P]),
+    'raft_gru_gate_q_backward_f32': (_I, [_P, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
+    'raft_gru_gate_r_backward_f32': (_I, [_P, _P, _P, C.c_int64, _P, _P, _P]),
+    'raft_axpby_f32': (_I, [C.c_float, _P, C.c_float, _P, _P, C.c_int64, _P]),
     'raft_conv2d_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I,
                              C.c_float, _P, _I, _P]),
     'raft_conv2d_winograd_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),

@@ -397,3 +397,197 @@ extern "C" int raft_conv2d_wgrad_f32(const float *x, int ldx, int cin, const flo
     }
     return RAFT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Elementwise pieces of the update block in training mode (reference update.py:51-67: SepConvGRU): the inference kernels
+// apply the gates in their convolution epilogues and keep nothing; the training forward runs the convolutions with a
+// linear epilogue and these kernels, so that z, r, q are available to the backward.
+//   gate_zr      z = sigmoid(a[:, :C]), r = sigmoid(a[:, C:2C]), rh = r * h
+//   gate_q       q = tanh(a), h' = (1 - z) h + z q
+//   gate_q_bwd   dh' -> dz_pre = dh' (q - h) z (1 - z),  dq_pre = dh' z (1 - q^2),  dh = dh' (1 - z)
+//   gate_r_bwd   d(rh) -> dr_pre = d(rh) h r (1 - r),  dh += d(rh) r
+//   axpby        out = alpha a + beta b   (gradient accumulation, the 0.25 of the mask head)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+__global__ void __launch_bounds__(256) gate_zr_kernel(const float *__restrict__ a, const float *__restrict__ h, int C, int64_t M,
+                                                      float *__restrict__ z, float *__restrict__ r, float *__restrict__ rh) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * C) return;
+    const int64_t m = i / C;
+    const int c = (int)(i - m * C);
+    const float zv = sigmoidf_(a[m * 2 * C + c]), rv = sigmoidf_(a[m * 2 * C + C + c]);
+    z[i] = zv;
+    r[i] = rv;
+    rh[i] = rv * h[i];
+}
+
+__global__ void __launch_bounds__(256) gate_q_kernel(const float *__restrict__ a, const float *__restrict__ z, const float *__restrict__ h,
+                                                     int64_t n, float *__restrict__ q, float *__restrict__ hn) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float qv = tanhf(a[i]), zv = z[i];
+    q[i] = qv;
+    hn[i] = (1.0f - zv) * h[i] + zv * qv;
+}
+
+__global__ void __launch_bounds__(256) gate_q_bwd_kernel(const float *__restrict__ dhn, const float *__restrict__ z, const float *__restrict__ q,
+                                                         const float *__restrict__ h, int64_t n, float *__restrict__ dz_pre,
+                                                         float *__restrict__ dq_pre, float *__restrict__ dh) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = dhn[i], zv = z[i], qv = q[i];
+    dz_pre[i] = g * (qv - h[i]) * zv * (1.0f - zv);
+    dq_pre[i] = g * zv * (1.0f - qv * qv);
+    dh[i] = g * (1.0f - zv);
+}
+
+__global__ void __launch_bounds__(256) gate_r_bwd_kernel(const float *__restrict__ drh, const float *__restrict__ r, const float *__restrict__ h,
+                                                         int64_t n, float *__restrict__ dr_pre, float *__restrict__ dh) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = drh[i], rv = r[i];
+    dr_pre[i] = g * h[i] * rv * (1.0f - rv);
+    dh[i] += g * rv;
+}
+
+__global__ void __launch_bounds__(256) axpby_kernel(float alpha, const float *__restrict__ a, float beta, const float *__restrict__ b,
+                                                    float *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+}   // namespace
+
+extern "C" int raft_gru_gate_zr_f32(const float *a_zr, const float *h, int C, int64_t M, float *z, float *r, float *rh, void *stream) {
+    RAFT_REQUIRE_PTR(a_zr); RAFT_REQUIRE_PTR(h); RAFT_REQUIRE_PTR(z); RAFT_REQUIRE_PTR(r); RAFT_REQUIRE_PTR(rh);
+    RAFT_REQUIRE(C > 0 && M > 0, RAFT_E_SHAPE);
+    gate_zr_kernel<<<raft_ceil_div(M * C, 256), 256, 0, (hipStream_t)stream>>>(a_zr, h, C, M, z, r, rh);
+    return raft_launch_status();
+}
+
+extern "C" int raft_gru_gate_q_f32(const float *a_q, const float *z, const float *h, int64_t n, float *q, float *h_new, void *stream) {
+    RAFT_REQUIRE_PTR(a_q); RAFT_REQUIRE_PTR(z); RAFT_REQUIRE_PTR(h); RAFT_REQUIRE_PTR(q); RAFT_REQUIRE_PTR(h_new);
+    RAFT_REQUIRE(n > 0, RAFT_E_SHAPE);
+    gate_q_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(a_q, z, h, n, q, h_new);
+    return raft_launch_status();
+}
+
+extern "C" int raft_gru_gate_q_backward_f32(const float *d_h_new, const float *z, const float *q, const float *h, int64_t n,
+                                            float *dz_pre, float *dq_pre, float *dh, void *stream) {
+    RAFT_REQUIRE_PTR(d_h_new); RAFT_REQUIRE_PTR(z); RAFT_REQUIRE_PTR(q); RAFT_REQUIRE_PTR(h);
+    RAFT_REQUIRE_PTR(dz_pre); RAFT_REQUIRE_PTR(dq_pre); RAFT_REQUIRE_PTR(dh);
+    RAFT_REQUIRE(n > 0, RAFT_E_SHAPE);
+    gate_q_bwd_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(d_h_new, z, q, h, n, dz_pre, dq_pre, dh);
+    return raft_launch_status();
+}
+
+extern "C" int raft_gru_gate_r_backward_f32(const float *d_rh, const float *r, const float *h, int64_t n, float *dr_pre, float *dh,
+                                            void *stream) {
+    RAFT_REQUIRE_PTR(d_rh); RAFT_REQUIRE_PTR(r); RAFT_REQUIRE_PTR(h); RAFT_REQUIRE_PTR(dr_pre); RAFT_REQUIRE_PTR(dh);
+    RAFT_REQUIRE(n > 0, RAFT_E_SHAPE);
+    gate_r_bwd_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(d_rh, r, h, n, dr_pre, dh);
+    return raft_launch_status();
+}
+
+extern "C" int raft_axpby_f32(float alpha, const float *a, float beta, const float *b, float *out, int64_t n, void *stream) {
+    RAFT_REQUIRE_PTR(a); RAFT_REQUIRE_PTR(out);
+    RAFT_REQUIRE(n > 0, RAFT_E_SHAPE);
+    axpby_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(alpha, a, beta, b, out, n);
+    return raft_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// convf1 (7x7, Cin = 2; reference update.py:93) backward.  0.4 % of the block's FLOPs: plain deterministic kernels.
+//   dgrad  d_flow[p][c] = sum_{ky,kx,n} dy[p - (ky-3, kx-3)][n] * K[ky][kx][c][n]      one wavefront per pixel, lanes over n
+//   wgrad  dK[k][n] = sum_p flow[p + tap(k)][c(k)] * dy[p][n]                            pixel slices -> ordered second-stage sum
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <int COUT>
+__global__ void __launch_bounds__(256) conv7x7_c2_dgrad_kernel(const float *__restrict__ dy, int ldy, const float *__restrict__ wk,
+                                                               int B, int H, int W, float *__restrict__ dflow) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * 4 + wv;
+    if (p >= (int64_t)B * H * W) return;
+    const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+    float a0 = 0.f, a1 = 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+        const int yy = y - (ky - 3);
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 7; ++kx) {
+            const int xx = x - (kx - 3);
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const float *d = dy + (((int64_t)b * H + yy) * W + xx) * ldy;
+            const float *k0 = wk + ((ky * 7 + kx) * 2) * COUT;
+            for (int n = lane; n < COUT; n += 64) {
+                const float g = d[n];
+                a0 = fmaf(g, k0[n], a0);
+                a1 = fmaf(g, k0[COUT + n], a1);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a0 += __shfl_xor(a0, o, 64);
+        a1 += __shfl_xor(a1, o, 64);
+    }
+    if (lane == 0) ((float2 *)dflow)[p] = make_float2(a0, a1);
+}
+
+constexpr int C7_SLICES = 256;
+template <int COUT>
+__global__ void __launch_bounds__(256) conv7x7_c2_wgrad_partial_kernel(const float *__restrict__ flow, const float *__restrict__ dy, int ldy,
+                                                                       int B, int H, int W, float *__restrict__ part) {
+    // thread = (k-group, n): n = tid % COUT, k walks 98 / (256 / COUT) values; pixels of the slice in order
+    constexpr int KG = 256 / COUT, KPT = (98 + KG - 1) / KG;
+    const int n = threadIdx.x % COUT, kg = threadIdx.x / COUT;
+    const int64_t M = (int64_t)B * H * W, lo = M * blockIdx.x / C7_SLICES, hi = M * (blockIdx.x + 1) / C7_SLICES;
+    float acc[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) acc[i] = 0.f;
+    for (int64_t p = lo; p < hi; ++p) {
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+        const float g = dy[p * ldy + n];
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int k = kg + i * KG;
+            if (k < 98) {
+                const int ky = k / 14, rem = k - ky * 14, kx = rem >> 1, c = rem & 1;
+                const int yy = y + ky - 3, xx = x + kx - 3;
+                const float f = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? flow[(((int64_t)b * H + yy) * W + xx) * 2 + c] : 0.f;
+                acc[i] = fmaf(f, g, acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int k = kg + i * KG;
+        if (k < 98) part[((int64_t)blockIdx.x * 98 + k) * COUT + n] = acc[i];
+    }
+}
+}   // namespace
+
+extern "C" int64_t raft_conv7x7_c2_wgrad_workspace_floats(int cout) { return cout > 0 ? (int64_t)C7_SLICES * (98 + 1) * cout : 0; }
+
+extern "C" int raft_conv7x7_c2_backward_f32(const float *flow, const float *dy, int ldy, const float *kernel, int cout, int B, int H,
+                                            int W, float *d_flow, float *d_kernel, float *d_bias, float *workspace, void *stream) {
+    RAFT_REQUIRE_PTR(flow); RAFT_REQUIRE_PTR(dy); RAFT_REQUIRE_PTR(kernel); RAFT_REQUIRE_PTR(d_flow);
+    RAFT_REQUIRE_PTR(d_kernel); RAFT_REQUIRE_PTR(d_bias); RAFT_REQUIRE_PTR(workspace);
+    RAFT_REQUIRE(B > 0 && H > 0 && W > 0 && ldy >= cout, RAFT_E_SHAPE);
+    RAFT_REQUIRE(cout == 64 || cout == 128, RAFT_E_UNSUPPORTED);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = (int64_t)B * H * W;
+    if (cout == 128) {
+        conv7x7_c2_dgrad_kernel<128><<<raft_ceil_div(M, 4), 256, 0, s>>>(dy, ldy, kernel, B, H, W, d_flow);
+        conv7x7_c2_wgrad_partial_kernel<128><<<C7_SLICES, 256, 0, s>>>(flow, dy, ldy, B, H, W, workspace);
+    } else {
+        conv7x7_c2_dgrad_kernel<64><<<raft_ceil_div(M, 4), 256, 0, s>>>(dy, ldy, kernel, B, H, W, d_flow);
+        conv7x7_c2_wgrad_partial_kernel<64><<<C7_SLICES, 256, 0, s>>>(flow, dy, ldy, B, H, W, workspace);
+    }
+    RAFT_TRY(raft_launch_status());
+    wgrad_reduce_kernel<<<raft_ceil_div(98 * cout, 256), 256, 0, s>>>(workspace, C7_SLICES, (int64_t)98 * cout, d_kernel);
+    float *bp = workspace + (int64_t)C7_SLICES * 98 * cout;
+    bias_grad_partial_kernel<<<C7_SLICES, 256, 0, s>>>(dy, ldy, cout, M, C7_SLICES, bp);
+    wgrad_reduce_kernel<<<raft_ceil_div(cout, 256), 256, 0, s>>>(bp, C7_SLICES, cout, d_bias);
+    return raft_launch_status();
+}

@@ -334,6 +334,24 @@ __global__ void __launch_bounds__(256) conv7x7_c2_kernel(const float *__restrict
     }
 }
 
+extern "C" int raft_conv7x7_c2_f32(const float *flow, const float *kernel, const float *bias, int cout, int B, int H, int W,
+                                   float *out, int ldo, void *stream) {
+    RAFT_REQUIRE_PTR(flow);
+    RAFT_REQUIRE_PTR(kernel);
+    RAFT_REQUIRE_PTR(bias);
+    RAFT_REQUIRE_PTR(out);
+    RAFT_REQUIRE(B > 0 && H > 0 && W > 0 && ldo >= cout, RAFT_E_SHAPE);
+    RAFT_REQUIRE(raft_aligned16(kernel), RAFT_E_ALIGN);
+    const int grid = B * ((H + 3) / 4) * ((W + 15) / 16);
+    if (cout == 128)
+        conv7x7_c2_kernel<128><<<grid, 256, 0, (hipStream_t)stream>>>(flow, kernel, bias, B, H, W, out, ldo);
+    else if (cout == 64)
+        conv7x7_c2_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>(flow, kernel, bias, B, H, W, out, ldo);
+    else
+        return RAFT_E_UNSUPPORTED;
+    return raft_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // flow_head.conv2: 3x3, Cout = 2, fused with the coordinate update of the loop
 //   delta = conv(x) + b; coords1 += delta; flow = coords1 - coords0    [update.py:14, model.py:97-102]

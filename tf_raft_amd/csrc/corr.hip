@@ -542,7 +542,8 @@ struct FusedLookupArgs {
 
 constexpr int FL_ROUNDS = 2, FL_QB = 14, FL_THREADS = 512, FL_LVLK = 84, FL_K = 4 * FL_LVLK, FL_LDA = FL_K + 4, FL_ROWS = 32;
 
-template <int R>
+// ABL (diagnostics, tools/fused_probe.py): 0 = the kernel; 1 = no lookup phase (A tile left zero); 2 = no MFMA phase
+template <int R, int ABL = 0>
 __global__ void __launch_bounds__(FL_THREADS, 1) lookup_convc1_kernel(FusedLookupArgs p) {
     using G = StripCfg<R>;
     constexpr int L = G::L, D = G::D, FP = G::FP, SP = G::SP, NR = G::NR;
@@ -557,12 +558,16 @@ __global__ void __launch_bounds__(FL_THREADS, 1) lookup_convc1_kernel(FusedLooku
     const int l = j / D, a = j - l * D;
     const int64_t qbase = (int64_t)blockIdx.x * QW;
 
+    if (ABL == 1) {
+        for (int i = tid; i < FL_ROWS * FL_LDA / 4; i += FL_THREADS) ((f32x4 *)sA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+    }
     // ---- phase A: the strip lookup, two rounds of fourteen queries; the gathers of BOTH rounds are issued up front
     float v[FL_ROUNDS][L][NR];
     int org[FL_ROUNDS][L][2];
     float2 cq[FL_ROUNDS];
 #pragma unroll
-    for (int rd = 0; rd < FL_ROUNDS; ++rd) {
+    for (int rd = 0; rd < (ABL == 1 ? 0 : FL_ROUNDS); ++rd) {
         const int64_t q0 = qbase + rd * FL_QB;
         const int64_t left = p.lk.nq - q0;
         const int nq_here = (int)(left < FL_QB ? (left < 1 ? 1 : left) : FL_QB);   // >= 1: loads stay in range
@@ -571,9 +576,10 @@ __global__ void __launch_bounds__(FL_THREADS, 1) lookup_convc1_kernel(FusedLooku
         cq[rd] = *(const float2 *)(p.lk.coords + 2 * (q0c + qc));
         strip_gather<R>(p.lk, q0c, qc, cq[rd], j, v[rd], org[rd]);
     }
-    for (int i = tid; i < FL_ROWS * FL_LDA / 4; i += FL_THREADS) ((f32x4 *)sA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ABL != 1)
+        for (int i = tid; i < FL_ROWS * FL_LDA / 4; i += FL_THREADS) ((f32x4 *)sA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int rd = 0; rd < FL_ROUNDS; ++rd) {
+    for (int rd = 0; rd < (ABL == 1 ? 0 : FL_ROUNDS); ++rd) {
         const int64_t left = p.lk.nq - (qbase + rd * FL_QB);
         const int nq_here = (int)(left < 0 ? 0 : (left < FL_QB ? left : FL_QB));
         const bool active = lk_thread && ql < nq_here;
@@ -602,6 +608,10 @@ __global__ void __launch_bounds__(FL_THREADS, 1) lookup_convc1_kernel(FusedLooku
     // ---- phase B: cor1 tile = relu(A . W + bias); wave wv owns channels 32 wv .. 32 wv + 31 (2 row x 2 column blocks)
     const int r16 = lane & 15, g4 = lane >> 4;
     const int n0 = wv * 32;
+    if (ABL == 2) {   // keep the lookup alive: one value per thread
+        if (tid < FL_ROWS && qbase + tid < p.lk.nq) p.out[(qbase + tid) * p.ldo] = sA[tid * FL_LDA + 5] + sA[tid * FL_LDA + 200];
+        return;
+    }
     f32x4 acc[2][2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -672,7 +682,14 @@ extern "C" int raft_lookup_convc1_f32(const float *pyr, const int64_t *level_off
     a.ldo = ldo;
     a.npad = npad;
     a.nvalid = nvalid;
-    lookup_convc1_kernel<4><<<raft_ceil_div(a.lk.nq, FL_QB * FL_ROUNDS), FL_THREADS, 0, (hipStream_t)stream>>>(a);
+    const int grid = raft_ceil_div(a.lk.nq, FL_QB * FL_ROUNDS);
+    const int abl = raft_opt(RAFT_OPT_LOOKUP_FUSED, 1);   // 1 = the kernel; 11 / 12 = diagnostic builds (tools/fused_probe.py)
+    if (abl == 11)
+        lookup_convc1_kernel<4, 1><<<grid, FL_THREADS, 0, (hipStream_t)stream>>>(a);
+    else if (abl == 12)
+        lookup_convc1_kernel<4, 2><<<grid, FL_THREADS, 0, (hipStream_t)stream>>>(a);
+    else
+        lookup_convc1_kernel<4, 0><<<grid, FL_THREADS, 0, (hipStream_t)stream>>>(a);
     return raft_launch_status();
 }
 

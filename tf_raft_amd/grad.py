@@ -103,3 +103,181 @@ def conv2d_backward(x, kernel, dy, y=None):
     check(lib.raft_conv2d_f32(_dev.ptr(dyp), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw, npad,
                               cin, 0, 1.0, _dev.ptr(dx), cin, _dev.stream_ptr()), 'conv2d dgrad')
     return _dev.wrap(dx), _dev.wrap(d_kernel), _dev.wrap(d_bias)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# second slice: one BasicUpdateBlock call (reference update.py:128-153) forward with saved activations + its backward
+# ------------------------------------------------------------------------------------------------------------------------
+
+def _conv_fwd(x, kernel, bias, act=0, scale=1.0):
+    """``[relu](conv2d(x, kernel) + bias) * scale`` through ``raft_conv2d_f32`` (stride 1, 'same'); x (B, H, W, Cin)."""
+    kernel = np.asarray(kernel, dtype=np.float32)
+    kh, kw, cin, cout = kernel.shape
+    B, H, W, c = x.shape
+    cpad = packing.round_up(cin, 32)
+    wp, b, npad = packing.pack_conv(kernel, bias, [(cin, cpad)])
+    xp = x
+    if cpad != c:
+        xp = torch.zeros((B, H, W, cpad), device=x.device, dtype=torch.float32)
+        xp[..., :c] = x
+    wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
+    out = torch.empty((B, H, W, cout), device=x.device, dtype=torch.float32)
+    check(_dev.lib().raft_conv2d_f32(_dev.ptr(xp), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw, npad,
+                                     cout, act, float(scale), _dev.ptr(out), cout, _dev.stream_ptr()), 'conv2d')
+    return out
+
+
+def _axpby(alpha, a, beta=0.0, b=None):
+    out = torch.empty_like(a)
+    check(_dev.lib().raft_axpby_f32(float(alpha), _dev.ptr(a), float(beta), _dev.ptr(b) if b is not None else None, _dev.ptr(out),
+                                    a.numel(), _dev.stream_ptr()), 'axpby')
+    return out
+
+
+def _conv_bwd(x, kernel, dy, y=None):
+    """``conv2d_backward`` for any channel counts: pads Cin / Cout to multiples of 4 around the kernels and trims."""
+    kernel = np.asarray(kernel, dtype=np.float32)
+    kh, kw, cin, cout = kernel.shape
+    ci4, co4 = packing.round_up(cin, 4), packing.round_up(cout, 4)
+    if ci4 != cin or co4 != cout:
+        kp = np.zeros((kh, kw, ci4, co4), np.float32)
+        kp[:, :, :cin, :cout] = kernel
+        B, H, W, _ = x.shape
+        xp = torch.zeros((B, H, W, ci4), device=x.device, dtype=torch.float32)
+        xp[..., :cin] = x
+        dyp = torch.zeros((B, H, W, co4), device=x.device, dtype=torch.float32)
+        dyp[..., :cout] = dy
+        yp = None
+        if y is not None:
+            yp = torch.zeros((B, H, W, co4), device=x.device, dtype=torch.float32)
+            yp[..., :cout] = y
+        dx, dk, db = conv2d_backward(xp, kp, dyp, y=yp)
+        t = lambda v: v.as_subclass(torch.Tensor)
+        return t(dx)[..., :cin].contiguous(), t(dk)[:, :, :cin, :cout].contiguous(), t(db)[:cout].contiguous()
+    dx, dk, db = conv2d_backward(x, kernel, dy, y=y)
+    return dx.as_subclass(torch.Tensor), dk.as_subclass(torch.Tensor), db.as_subclass(torch.Tensor)
+
+
+def basic_update_block_forward(weights, net, inp, corr, flow, prefix='update_block'):
+    """``BasicUpdateBlock([net, inp, corr, flow])`` (reference update.py:143-153) in TRAINING form: every layer a generic
+    HIP convolution with a linear / relu epilogue, the GRU gates as separate kernels, every activation the backward needs
+    kept.  Returns ``(net, mask, delta_flow, saved)``.  (The inference path fuses gates and branches into its kernels and
+    keeps nothing; both compute the same function: ``tests/test_gpu_backward.py`` checks this one against the oracle.)"""
+    lib = _dev.lib()
+    p = prefix
+    w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p)}
+    net, inp, corr, flow = (_f32(t) for t in (net, inp, corr, flow))
+    B, H, W, _ = net.shape
+    M = B * H * W
+    s = {'net0': net, 'inp': inp, 'corr': corr, 'flow': flow}
+    conv = lambda name, x, act=0, scale=1.0: _conv_fwd(x, w[f'{p}/{name}/kernel'], w[f'{p}/{name}/bias'], act, scale)
+    s['cor1'] = conv('encoder/convc1', corr, 1)
+    s['cor2'] = conv('encoder/convc2', s['cor1'], 1)
+    k7 = _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, 128))
+    b7 = _dev.to_device(w[f'{p}/encoder/convf1/bias'])
+    s['flo1'] = torch.empty((B, H, W, 128), device=net.device, dtype=torch.float32)
+    check(lib.raft_conv7x7_c2_f32(_dev.ptr(flow), _dev.ptr(k7), _dev.ptr(b7), 128, B, H, W, _dev.ptr(s['flo1']), 128,
+                                  _dev.stream_ptr()), 'conv7x7_c2')
+    s['flo2'] = conv('encoder/convf2', s['flo1'], 1)
+    s['corflo'] = torch.cat([s['cor2'], s['flo2']], dim=-1)                       # update.py:104
+    s['mot'] = conv('encoder/conv', s['corflo'], 1)
+    x = torch.cat([inp, s['mot'], flow], dim=-1).contiguous()                      # update.py:106, 146: [inp | motion 126 | flow 2]
+    s['x'] = x
+    h = net
+    for g in ('1', '2'):                                                           # update.py:51-67
+        kzr = np.concatenate([w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3)
+        bzr = np.concatenate([w[f'{p}/gru/convz{g}/bias'], w[f'{p}/gru/convr{g}/bias']])
+        hx = torch.cat([h, x], dim=-1).contiguous()
+        a_zr = _conv_fwd(hx, kzr, bzr)
+        z, r, rh = (torch.empty_like(h) for _ in range(3))
+        check(lib.raft_gru_gate_zr_f32(_dev.ptr(a_zr), _dev.ptr(h), 128, M, _dev.ptr(z), _dev.ptr(r), _dev.ptr(rh),
+                                       _dev.stream_ptr()), 'gate_zr')
+        rhx = torch.cat([rh, x], dim=-1).contiguous()
+        a_q = conv(f'gru/convq{g}', rhx)
+        q, hn = torch.empty_like(h), torch.empty_like(h)
+        check(lib.raft_gru_gate_q_f32(_dev.ptr(a_q), _dev.ptr(z), _dev.ptr(h), h.numel(), _dev.ptr(q), _dev.ptr(hn),
+                                      _dev.stream_ptr()), 'gate_q')
+        s[f'h_in{g}'], s[f'hx{g}'], s[f'rhx{g}'], s[f'z{g}'], s[f'r{g}'], s[f'q{g}'] = h, hx, rhx, z, r, q
+        h = hn
+    s['net'] = h
+    s['fh'] = conv('flow_head/conv1', h, 1)
+    delta = conv('flow_head/conv2', s['fh'])
+    s['m0'] = conv('mask/0', h, 1)
+    mask = conv('mask/2', s['m0'], 0, 0.25)                                        # update.py:152
+    return _dev.wrap(h), _dev.wrap(mask), _dev.wrap(delta), s
+
+
+def basic_update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update_block'):
+    """Backward of ``basic_update_block_forward``: upstream gradients of its three outputs -> gradients w.r.t. the four
+    inputs (``net``, ``inp``, ``corr``, ``flow``) and w.r.t. every kernel and bias of the block (dict under the weight
+    names).  Every arithmetic step is a HIP kernel (convolution dgrad / wgrad, gate and relu backward, axpby); torch only
+    concatenates, slices and allocates."""
+    lib = _dev.lib()
+    p = prefix
+    w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p)}
+    s = saved
+    d_net, d_mask, d_delta = (_f32(t) for t in (d_net, d_mask, d_delta))
+    grads = {}
+    B, H, W, _ = d_net.shape
+    n_h = d_net.numel()
+
+    def conv_b(name, x, dy, y=None, kernel=None):
+        k = w[f'{p}/{name}/kernel'] if kernel is None else kernel
+        dx, dk, db = _conv_bwd(x, k, dy, y)
+        if kernel is None:
+            grads[f'{p}/{name}/kernel'], grads[f'{p}/{name}/bias'] = dk, db
+        return dx, dk, db
+
+    # mask head: mask = 0.25 * mask.2(relu(mask.0(net)))                          update.py:137-141, 152
+    dm = _axpby(0.25, d_mask)
+    dm0, _, _ = conv_b('mask/2', s['m0'], dm)
+    dh_a, _, _ = conv_b('mask/0', s['net'], dm0, y=s['m0'])
+    # flow head: delta = conv2(relu(conv1(net)))                                  update.py:13-14
+    dfh, _, _ = conv_b('flow_head/conv2', s['fh'], d_delta)
+    dh_b, _, _ = conv_b('flow_head/conv1', s['net'], dfh, y=s['fh'])
+    dh = _axpby(1.0, d_net, 1.0, dh_a)
+    dh = _axpby(1.0, dh, 1.0, dh_b)
+    dx_total = None
+    for g in ('2', '1'):                                                           # SepConvGRU, vertical pass first
+        h_in, z, r, q = s[f'h_in{g}'], s[f'z{g}'], s[f'r{g}'], s[f'q{g}']
+        dz_pre, dq_pre, dh_in = (torch.empty_like(h_in) for _ in range(3))
+        check(lib.raft_gru_gate_q_backward_f32(_dev.ptr(dh), _dev.ptr(z), _dev.ptr(q), _dev.ptr(h_in), n_h, _dev.ptr(dz_pre),
+                                               _dev.ptr(dq_pre), _dev.ptr(dh_in), _dev.stream_ptr()), 'gate_q_backward')
+        d_rhx, _, _ = conv_b(f'gru/convq{g}', s[f'rhx{g}'], dq_pre)
+        d_rh = d_rhx[..., :128].contiguous()
+        dx_q = d_rhx[..., 128:].contiguous()
+        dr_pre = torch.empty_like(h_in)
+        check(lib.raft_gru_gate_r_backward_f32(_dev.ptr(d_rh), _dev.ptr(r), _dev.ptr(h_in), n_h, _dev.ptr(dr_pre), _dev.ptr(dh_in),
+                                               _dev.stream_ptr()), 'gate_r_backward')
+        kzr = np.concatenate([w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3)
+        d_zr = torch.cat([dz_pre, dr_pre], dim=-1).contiguous()
+        d_hx, dk, db = conv_b(None, s[f'hx{g}'], d_zr, kernel=kzr)
+        grads[f'{p}/gru/convz{g}/kernel'], grads[f'{p}/gru/convr{g}/kernel'] = dk[..., :128].contiguous(), dk[..., 128:].contiguous()
+        grads[f'{p}/gru/convz{g}/bias'], grads[f'{p}/gru/convr{g}/bias'] = db[:128].contiguous(), db[128:].contiguous()
+        dh = _axpby(1.0, dh_in, 1.0, d_hx[..., :128].contiguous())
+        dx_g = _axpby(1.0, dx_q, 1.0, d_hx[..., 128:].contiguous())
+        dx_total = dx_g if dx_total is None else _axpby(1.0, dx_total, 1.0, dx_g)
+    d_inp = dx_total[..., :128].contiguous()
+    d_mot = dx_total[..., 128:254].contiguous()
+    d_flow_x = dx_total[..., 254:256].contiguous()
+    # motion encoder                                                               update.py:97-106
+    d_corflo, _, _ = conv_b('encoder/conv', s['corflo'], d_mot, y=s['mot'])
+    d_cor2 = d_corflo[..., :192].contiguous()
+    d_flo2 = d_corflo[..., 192:].contiguous()
+    d_cor1, _, _ = conv_b('encoder/convc2', s['cor1'], d_cor2, y=s['cor2'])
+    d_corr, _, _ = conv_b('encoder/convc1', s['corr'], d_cor1, y=s['cor1'])
+    d_flo1, _, _ = conv_b('encoder/convf2', s['flo1'], d_flo2, y=s['flo2'])
+    masked = torch.empty_like(d_flo1)
+    check(lib.raft_relu_backward_f32(_dev.ptr(s['flo1']), _dev.ptr(d_flo1), _dev.ptr(masked), masked.numel(), _dev.stream_ptr()),
+          'relu_backward')
+    k7 = _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, 128))
+    d_flow_f = torch.empty((B, H, W, 2), device=d_net.device, dtype=torch.float32)
+    dk7 = torch.empty((98, 128), device=d_net.device, dtype=torch.float32)
+    db7 = torch.empty((128,), device=d_net.device, dtype=torch.float32)
+    ws = torch.empty((int(lib.raft_conv7x7_c2_wgrad_workspace_floats(128)),), device=d_net.device, dtype=torch.float32)
+    check(lib.raft_conv7x7_c2_backward_f32(_dev.ptr(s['flow']), _dev.ptr(masked), 128, _dev.ptr(k7), 128, B, H, W, _dev.ptr(d_flow_f),
+                                           _dev.ptr(dk7), _dev.ptr(db7), _dev.ptr(ws), _dev.stream_ptr()), 'conv7x7_c2_backward')
+    grads[f'{p}/encoder/convf1/kernel'], grads[f'{p}/encoder/convf1/bias'] = dk7.view(7, 7, 2, 128), db7
+    d_flow = _axpby(1.0, d_flow_x, 1.0, d_flow_f)
+    return {'net': _dev.wrap(dh), 'inp': _dev.wrap(d_inp), 'corr': _dev.wrap(d_corr), 'flow': _dev.wrap(d_flow)}, \
+        {k: _dev.wrap(v) for k, v in grads.items()}
