@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 203          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 204          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -472,6 +472,13 @@ int raft_gru_gate_r_backward_f32(const float *d_rh, const float *r, const float 
                                  void *stream);
 /* out = alpha * a + beta * b (b may be NULL): gradient accumulation where two branches meet, the 0.25 of the mask head. */
 int raft_axpby_f32(float alpha, const float *a, float beta, const float *b, float *out, int64_t n, void *stream);
+
+/* Backward of raft_upsample_convex_f32 (RAFT.upsample_flow, model.py:39-66): d_up (B, 8h, 8w, 2) -> d_flow (B, h, w, 2)
+ * and d_mask (B, h, w, 576), both overwritten.  Deterministic (the scatter into the 3x3 neighbours is a gather over a
+ * per-pixel, per-tap scratch); workspace raft_upsample_convex_backward_workspace_floats() floats. */
+int64_t raft_upsample_convex_backward_workspace_floats(int B, int h, int w);
+int raft_upsample_convex_backward_f32(const float *flow, const float *mask, const float *d_up, int B, int h, int w,
+                                      float *d_flow, float *d_mask, float *workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -195,3 +195,95 @@ def test_basic_update_block_backward_matches_autograd(rng, shape):
         assert rel <= 5e-5, (name, rel)
     report(f'update block backward {shape}', worst_rel_err_over_34_gradients=worst)
     assert worst <= 5e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 7, 9), (1, 6, 8)])
+def test_upsample_convex_backward_matches_autograd(rng, shape):
+    from oracle.model import upsample_flow
+    from tf_raft_amd import grad
+    B, h, w = shape
+    flow = rng.normal(size=(B, h, w, 2)).astype(np.float32)
+    mask = rng.normal(size=(B, h, w, 576)).astype(np.float32)
+    d_up = rng.normal(size=(B, 8 * h, 8 * w, 2)).astype(np.float32)
+    tf, tm = torch.tensor(flow, dtype=torch.float64, requires_grad=True), torch.tensor(mask, dtype=torch.float64, requires_grad=True)
+    upsample_flow(tf, tm).backward(torch.tensor(d_up, dtype=torch.float64))
+    d_flow, d_mask = grad.upsample_flow_backward(flow, mask, d_up)
+    for name, got, want in (('d_flow', d_flow, tf.grad), ('d_mask', d_mask, tm.grad)):
+        want = want.numpy()
+        rel = float(np.abs(_np(got) - want).max() / max(1.0, np.abs(want).max()))
+        report(f'upsample_convex backward {shape} {name}', rel_err=rel, scale=float(np.abs(want).max()))
+        assert rel <= 1e-5
+
+
+def test_loop_backward_through_time_matches_autograd(rng):
+    """Third slice: the prediction loop of RAFT.call (reference model.py:91-109) in training form, 3 iterations, and its
+    backward through time for the gradient of ``sequence_loss``: lookup -> update block -> coords update -> convex
+    upsampling, with the gradient flowing through the lookup coordinates of every iteration (the reference has no
+    stop_gradient).  Checked against torch autograd through the oracle's loop (float64) on the same correlation volume:
+    d loss / d {net0, inp, every level of the volume, all 30 update-block kernels and biases}.  Conditioned weights keep the
+    lookup away from its discontinuities."""
+    import oracle
+    from oracle.layers import W, basic_update_block
+    from oracle.model import upsample_flow
+    from tf_raft_amd import grad
+    from tf_raft_amd import weights as wm
+    from tf_raft_amd.layers.corr import CorrBlock
+    B, h, w, C, iters = 1, 16, 24, 32, 3
+    wts_all = wm.condition_weights('raft', wm.init_weights('raft', seed=3))
+    wts = {k: v for k, v in wts_all.items() if k.startswith('update_block')}
+    f1 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    f2 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    net0 = np.tanh(rng.normal(size=(B, h, w, 128))).astype(np.float32)
+    inp = np.maximum(rng.normal(size=(B, h, w, 128)), 0).astype(np.float32)
+    flow_gt = (rng.normal(size=(B, 8 * h, 8 * w, 2)) * 2).astype(np.float32)
+    valid = rng.uniform(size=(B, 8 * h, 8 * w)) < 0.9
+    # ---- oracle side (float64, autograd)
+    ref = oracle.CorrBlock(torch.tensor(f1, dtype=torch.float64), torch.tensor(f2, dtype=torch.float64), 4, 4)
+    pyr = [lvl.detach().clone().requires_grad_(True) for lvl in ref.corr_pyramid]
+    ref.corr_pyramid = pyr
+    ow = W(wts, torch.float64)
+    for t in ow.t.values():
+        t.requires_grad_(True)
+    tnet = torch.tensor(net0, dtype=torch.float64, requires_grad=True)
+    tinp = torch.tensor(inp, dtype=torch.float64, requires_grad=True)
+    coords0 = oracle.coords_grid(B, h, w, torch.float64)
+    coords1, net, preds = coords0.clone(), tnet, []
+    for _ in range(iters):
+        corr = ref.retrieve(coords1)
+        net, mask, delta = basic_update_block(ow, 'update_block', net, tinp, corr, coords1 - coords0)
+        coords1 = coords1 + delta
+        preds.append(upsample_flow(coords1 - coords0, mask))
+    loss = _torch_sequence_loss(torch.tensor(flow_gt, dtype=torch.float64), torch.tensor(valid), preds, 0.8, 400)
+    loss.backward()
+    # ---- device side
+    dev = CorrBlock(f1, f2, 4, 4)
+    for l in range(4):
+        dev._set_level(l, pyr[l].detach().to(torch.float32))
+    gpreds, tape = grad.loop_forward(wts, dev, net0, inp, iters)
+    for i in range(iters):
+        err = float(np.abs(_np(gpreds[i]) - preds[i].detach().numpy()).max())
+        report(f'loop training forward prediction {i}', max_abs_vs_f64=err)
+        assert err <= 1e-4
+    d_preds = grad.sequence_loss_grad((flow_gt, valid), gpreds, gamma=0.8, max_flow=400)
+    d_net0, d_inp, d_pyr, wg = grad.loop_backward(wts, dev, tape, d_preds)
+    worst = 0.0
+
+    def cmp(name, got, want):
+        nonlocal worst
+        want = want.numpy()
+        rel = float(np.abs(_np(got) - want).max() / max(np.abs(want).max(), 1e-12))
+        report(f'loop backward {name}', rel_err=rel, scale=float(np.abs(want).max()))
+        worst = max(worst, rel)
+        assert rel <= 2e-3, (name, rel)
+
+    cmp('d_net0', d_net0, tnet.grad)
+    cmp('d_inp', d_inp, tinp.grad)
+    for l, lvl in enumerate(dev.untile_pyramid(d_pyr)):
+        cmp(f'd_pyramid[{l}]', lvl, pyr[l].grad)
+    assert len(wg) == 30
+    for name in sorted(wg):
+        want = ow.t[name].grad.numpy()
+        rel = float(np.abs(_np(wg[name]) - want).max() / max(np.abs(want).max(), 1e-12))
+        worst = max(worst, rel)
+        assert rel <= 2e-3, (name, rel)
+    report('loop backward through time, 3 iterations', worst_rel_err=worst)

@@ -591,3 +591,98 @@ extern "C" int raft_conv7x7_c2_backward_f32(const float *flow, const float *dy, 
     wgrad_reduce_kernel<<<raft_ceil_div(cout, 256), 256, 0, s>>>(bp, C7_SLICES, cout, d_bias);
     return raft_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Convex upsampling backward (reference model.py:39-66):  up[8y+i, 8x+j, c] = sum_k p_k * 8 * flow[y+ky-1, x+kx-1, c],
+// p = softmax_k(mask[y, x, (i*8+j)*9 + k]), zero padding outside the map.  For the upstream gradient g = d_up[8y+i, 8x+j]:
+//   s_k = 8 * <flow_nb(k), g>,   d_mask[.., k] = p_k * (s_k - sum_k' p_k' s_k'),
+//   d_flow[nb(k)] += 8 * sum_{i,j} p_k * g.
+// One wavefront per coarse pixel, lane = sub-pixel (i, j).  The scatter into the neighbours is made deterministic in two
+// steps: the wave writes its nine 2-vectors to T[pixel][k] (reduced over the lanes in a fixed butterfly), a second kernel
+// GATHERS d_flow[p] = sum_k T[p - offset(k)][k].
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) upsample_convex_bwd_kernel(const float *__restrict__ flow, const float *__restrict__ mask,
+                                                                  const float *__restrict__ d_up, int B, int h, int w,
+                                                                  float *__restrict__ d_mask, float *__restrict__ T) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * 4 + wv;
+    if (p >= (int64_t)B * h * w) return;
+    const int x = (int)(p % w), y = (int)((p / w) % h);
+    const int64_t b = p / ((int64_t)w * h);
+    const int i = lane >> 3, j = lane & 7;
+    const float *m = mask + p * 576 + lane * 9;
+    float mk[9], mx = -3.4e38f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        mk[k] = m[k];
+        mx = fmaxf(mx, mk[k]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        mk[k] = __expf(mk[k] - mx);
+        sum += mk[k];
+    }
+    const float inv = 1.0f / sum;
+    const float2 g = *(const float2 *)(d_up + (((b * 8 * h + 8 * y + i) * (int64_t)(8 * w)) + 8 * x + j) * 2);
+    float s[9], sbar = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        mk[k] *= inv;
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        float2 f = make_float2(0.f, 0.f);
+        if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) f = *(const float2 *)(flow + ((b * h + yy) * (int64_t)w + xx) * 2);
+        s[k] = 8.0f * (f.x * g.x + f.y * g.y);
+        sbar = fmaf(mk[k], s[k], sbar);
+    }
+    float *dm = d_mask + p * 576 + lane * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        dm[k] = mk[k] * (s[k] - sbar);
+        float tx = 8.0f * mk[k] * g.x, ty = 8.0f * mk[k] * g.y;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            tx += __shfl_xor(tx, o, 64);
+            ty += __shfl_xor(ty, o, 64);
+        }
+        if (lane == 0) *(float2 *)(T + (p * 9 + k) * 2) = make_float2(tx, ty);
+    }
+}
+
+__global__ void __launch_bounds__(256) upsample_convex_bwd_gather_kernel(const float *__restrict__ T, int B, int h, int w,
+                                                                         float *__restrict__ d_flow) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (int64_t)B * h * w) return;
+    const int x = (int)(p % w), y = (int)((p / w) % h);
+    const int64_t b = p / ((int64_t)w * h);
+    float ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {   // pixel q = p - offset(k) used p as its neighbour k
+        const int yy = y - (k / 3 - 1), xx = x - (k % 3 - 1);
+        if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+            const float2 t = *(const float2 *)(T + ((((b * h + yy) * (int64_t)w + xx)) * 9 + k) * 2);
+            ax += t.x;
+            ay += t.y;
+        }
+    }
+    *(float2 *)(d_flow + p * 2) = make_float2(ax, ay);
+}
+}   // namespace
+
+extern "C" int64_t raft_upsample_convex_backward_workspace_floats(int B, int h, int w) {
+    return (B > 0 && h > 0 && w > 0) ? (int64_t)B * h * w * 18 : 0;
+}
+
+extern "C" int raft_upsample_convex_backward_f32(const float *flow, const float *mask, const float *d_up, int B, int h, int w,
+                                                 float *d_flow, float *d_mask, float *workspace, void *stream) {
+    RAFT_REQUIRE_PTR(flow); RAFT_REQUIRE_PTR(mask); RAFT_REQUIRE_PTR(d_up);
+    RAFT_REQUIRE_PTR(d_flow); RAFT_REQUIRE_PTR(d_mask); RAFT_REQUIRE_PTR(workspace);
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = (int64_t)B * h * w;
+    upsample_convex_bwd_kernel<<<raft_ceil_div(M, 4), 256, 0, s>>>(flow, mask, d_up, B, h, w, d_mask, workspace);
+    RAFT_TRY(raft_launch_status());
+    upsample_convex_bwd_gather_kernel<<<raft_ceil_div(M, 256), 256, 0, s>>>(workspace, B, h, w, d_flow);
+    return raft_launch_status();
+}

@@ -281,3 +281,74 @@ def basic_update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='
     d_flow = _axpby(1.0, d_flow_x, 1.0, d_flow_f)
     return {'net': _dev.wrap(dh), 'inp': _dev.wrap(d_inp), 'corr': _dev.wrap(d_corr), 'flow': _dev.wrap(d_flow)}, \
         {k: _dev.wrap(v) for k, v in grads.items()}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# third slice: the prediction loop of RAFT.call in training form and its backward through time (reference model.py:91-109)
+# ------------------------------------------------------------------------------------------------------------------------
+
+def upsample_flow_backward(flow, mask, d_up):
+    """Backward of ``RAFT.upsample_flow(flow, mask)`` (reference model.py:39-66): ``(d_flow, d_mask)``."""
+    flow, mask, d_up = _f32(flow), _f32(mask), _f32(d_up)
+    B, h, w, _ = flow.shape
+    lib = _dev.lib()
+    d_flow, d_mask = torch.empty_like(flow), torch.empty_like(mask)
+    ws = torch.empty((int(lib.raft_upsample_convex_backward_workspace_floats(B, h, w)),), device=flow.device, dtype=torch.float32)
+    check(lib.raft_upsample_convex_backward_f32(_dev.ptr(flow), _dev.ptr(mask), _dev.ptr(d_up), B, h, w, _dev.ptr(d_flow),
+                                                _dev.ptr(d_mask), _dev.ptr(ws), _dev.stream_ptr()), 'upsample_convex_backward')
+    return d_flow, d_mask
+
+
+def loop_forward(weights, corr_block, net0, inp, iters, prefix='update_block'):
+    """The ``for i in range(iters)`` loop of ``RAFT.call`` (reference model.py:91-109) in training form, from the correlation
+    volume, ``net0 = tanh(.)`` and ``inp = relu(.)`` on: lookup -> update block -> coords1 += delta -> convex upsampling.
+    Returns ``(flow_predictions, tape)``; the tape holds what ``loop_backward`` needs."""
+    from .layers.corr import coords_grid
+    net, inp = _f32(net0), _f32(inp)
+    B, h, w, _ = net.shape
+    coords0 = coords_grid(B, h, w).as_subclass(torch.Tensor)
+    coords1 = coords0.clone()
+    preds, tape = [], []
+    lib = _dev.lib()
+    for _ in range(iters):
+        corr = corr_block.retrieve(coords1).as_subclass(torch.Tensor)
+        flow = _axpby(1.0, coords1, -1.0, coords0)
+        net_n, mask, delta, saved = basic_update_block_forward(weights, net, inp, corr, flow, prefix)
+        coords_n = _axpby(1.0, coords1, 1.0, delta.as_subclass(torch.Tensor))
+        flow_n = _axpby(1.0, coords_n, -1.0, coords0)
+        up = torch.empty((B, 8 * h, 8 * w, 2), device=net.device, dtype=torch.float32)
+        check(lib.raft_upsample_convex_f32(_dev.ptr(flow_n), _dev.ptr(mask.as_subclass(torch.Tensor)), B, h, w, _dev.ptr(up),
+                                           _dev.stream_ptr()), 'upsample_convex')
+        tape.append(dict(coords1=coords1, saved=saved, flow_n=flow_n, mask=mask.as_subclass(torch.Tensor)))
+        preds.append(_dev.wrap(up))
+        net, coords1 = net_n.as_subclass(torch.Tensor), coords_n
+    return preds, tape
+
+
+def loop_backward(weights, corr_block, tape, d_preds, prefix='update_block'):
+    """Backward through time of ``loop_forward`` for the upstream gradients ``d_preds`` of the flow predictions (e.g.
+    ``sequence_loss_grad``).  The reference does not stop the gradient at ``coords1`` (model.py:93-106), so it flows
+    through the lookup coordinates of every iteration.  Returns ``(d_net0, d_inp, d_pyramid, weight_grads)``."""
+    iters = len(tape)
+    d_c = None          # gradient w.r.t. coords1 after the current iteration
+    d_net = None
+    d_inp = None
+    d_pyr = None
+    wg = None
+    for i in reversed(range(iters)):
+        t = tape[i]
+        d_flowlow, d_mask = upsample_flow_backward(t['flow_n'], t['mask'], d_preds[i])
+        d_c = d_flowlow if d_c is None else _axpby(1.0, d_c, 1.0, d_flowlow)
+        if d_net is None:
+            d_net = torch.zeros_like(t['saved']['net'])
+        din, dw = basic_update_block_backward(weights, t['saved'], d_net, d_mask, d_c, prefix)
+        d_coords, d_pyr = corr_lookup_backward(corr_block, t['coords1'], din['corr'], d_pyramid=d_pyr)
+        d_c = _axpby(1.0, d_c, 1.0, din['flow'].as_subclass(torch.Tensor))
+        d_c = _axpby(1.0, d_c, 1.0, d_coords.as_subclass(torch.Tensor))
+        d_net = din['net'].as_subclass(torch.Tensor)
+        d_inp = din['inp'].as_subclass(torch.Tensor) if d_inp is None else _axpby(1.0, d_inp, 1.0, din['inp'].as_subclass(torch.Tensor))
+        if wg is None:
+            wg = {k: v.as_subclass(torch.Tensor) for k, v in dw.items()}
+        else:
+            wg = {k: _axpby(1.0, wg[k], 1.0, v.as_subclass(torch.Tensor).contiguous()) for k, v in dw.items()}
+    return _dev.wrap(d_net), _dev.wrap(d_inp), d_pyr, {k: _dev.wrap(v) for k, v in wg.items()}
