@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 204          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 205          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -479,6 +479,18 @@ int raft_axpby_f32(float alpha, const float *a, float beta, const float *b, floa
 int64_t raft_upsample_convex_backward_workspace_floats(int B, int h, int w);
 int raft_upsample_convex_backward_f32(const float *flow, const float *mask, const float *d_up, int B, int h, int w,
                                       float *d_flow, float *d_mask, float *workspace, void *stream);
+
+/* ---- optimizer side of train_step (model.py:131-136): tf.clip_by_global_norm + tfa.optimizers.AdamW (tfa 0.11.1) */
+
+/* *out (+)= sum of x[i]^2 in float64, deterministic; accumulate != 0 adds to the value already in *out (the global norm
+ * runs over every gradient tensor).  workspace: raft_sumsq_workspace_doubles() doubles. */
+int64_t raft_sumsq_workspace_doubles(void);
+int raft_sumsq_f32(const float *x, int64_t n, int accumulate, double *out, double *workspace, void *stream);
+/* One AdamW step on one tensor, tensorflow-addons 0.11.1 semantics: var -= weight_decay * var (decoupled, not scaled by
+ * the learning rate); g = grad * clip_norm / max(sqrt(*global_norm_sq), clip_norm) (global_norm_sq NULL: no clipping);
+ * m, v Adam moments; var -= lr_t * m / (sqrt(v) + epsilon) with lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) from the caller. */
+int raft_adamw_step_f32(float *var, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1, float beta2,
+                        float epsilon, float weight_decay, const double *global_norm_sq, float clip_norm, void *stream);
 
 #ifdef __cplusplus
 }

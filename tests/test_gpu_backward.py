@@ -295,3 +295,108 @@ def test_loop_backward_through_time_matches_autograd(rng):
         worst_w = max(worst_w, rel2)
         assert rel2 <= 5e-3, (name, rel2)
     report('loop backward through time, 3 iterations', worst_rel_err_inputs=worst, worst_rel_l2_weights=worst_w)
+
+
+def _reference_train_steps(wts, batches, iters, lr_fn, wd, clip_norm, n_steps):
+    """The reference's train_step (model.py:126-144) restricted to the update block, on the oracle in float64: forward with
+    frozen encoders in inference mode, sequence_loss, autograd, tf.clip_by_global_norm, tfa AdamW (tfa 0.11.1: decoupled
+    decay not scaled by the learning rate; Keras Adam, epsilon 1e-7).  Returns (losses, updated update-block weights)."""
+    import oracle
+    from oracle.layers import W, basic_update_block, encoder
+    from oracle.model import upsample_flow
+    names = sorted(k for k in wts if k.startswith('update_block'))
+    var = {k: torch.tensor(wts[k], dtype=torch.float64) for k in names}
+    m = {k: torch.zeros_like(v) for k, v in var.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in var.items()}
+    frozen = W({k: val for k, val in wts.items() if not k.startswith('update_block')}, torch.float64)
+    losses = []
+    for step in range(n_steps):
+        i1, i2, flow_gt, valid = batches[step]
+        with torch.no_grad():
+            x1 = 2 * (torch.tensor(i1, dtype=torch.float64) / 255.0) - 1.0
+            x2 = 2 * (torch.tensor(i2, dtype=torch.float64) / 255.0) - 1.0
+            f1, f2 = encoder(frozen, 'fnet', [x1, x2])
+            corr_blk = oracle.CorrBlock(f1, f2, 4, 4)
+            cnet = encoder(frozen, 'cnet', x1)
+            net, inp = torch.tanh(cnet[..., :128]), torch.relu(cnet[..., 128:])
+        ow = W({}, torch.float64)
+        ow.t = {k: val.clone().requires_grad_(True) for k, val in var.items()}
+        B, h, w, _ = net.shape
+        coords0 = oracle.coords_grid(B, h, w, torch.float64)
+        coords1, preds = coords0.clone(), []
+        for _ in range(iters):
+            corr = corr_blk.retrieve(coords1)
+            net, mask, delta = basic_update_block(ow, 'update_block', net, inp, corr, coords1 - coords0)
+            coords1 = coords1 + delta
+            preds.append(upsample_flow(coords1 - coords0, mask))
+        loss = _torch_sequence_loss(torch.tensor(flow_gt, dtype=torch.float64), torch.tensor(valid), preds, 0.8, 400)
+        loss.backward()
+        losses.append(float(loss))
+        g = {k: ow.t[k].grad for k in names}
+        gnorm = torch.sqrt(sum((gg ** 2).sum() for gg in g.values()))
+        scale = clip_norm / max(float(gnorm), clip_norm)
+        t = step + 1
+        lr = lr_fn(step)
+        lr_t = lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        for k in names:
+            gk = g[k] * scale
+            w_ = var[k] - wd * var[k]
+            m[k] = 0.9 * m[k] + 0.1 * gk
+            v2[k] = 0.999 * v2[k] + 0.001 * gk * gk
+            var[k] = w_ - lr_t * m[k] / (torch.sqrt(v2[k]) + 1e-7)
+    return losses, {k: v.numpy() for k, v in var.items()}
+
+
+def test_train_step_update_block_matches_reference_semantics(rng):
+    """RAFT.train_step with trainable='update_block' (reference model.py:126-144, train_sintel.py:83-102 optimizer setup):
+    two steps at (1, 64, 96), iters = 3, cyclical learning rate + AdamW + global-norm clipping, against the same procedure
+    on the float64 oracle with autograd.  Losses agree to 1e-4 relative; the updated weights are compared through the
+    UPDATE they received (Adam's first steps are lr * sign(g)-like, so an update is O(lr) whatever the gradient scale:
+    elements whose gradient is at rounding level may take a different sign)."""
+    import tf_raft_amd
+    from tf_raft_amd import losses, training
+    from tf_raft_amd import weights as wm
+    B, H, W, iters, n_steps = 1, 64, 96, 3, 2
+    wts = wm.condition_weights('raft', wm.init_weights('raft', seed=5))
+    batches = []
+    for _ in range(n_steps):
+        i1 = rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32)
+        i2 = rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32)
+        batches.append((i1, i2, (rng.normal(size=(B, H, W, 2)) * 2).astype(np.float32), rng.uniform(size=(B, H, W)) < 0.9))
+    lr0, wd, clip = 4e-4, 1e-4, 1.0
+    sched = training.CyclicalLearningRate(lr0, 2 * lr0, step_size=1000, scale_fn=training.first_cycle_scaler, scale_mode='cycle')
+    assert sched(0) == lr0 and abs(sched(1000) - 2 * lr0) < 1e-12 and sched(2000) == lr0 and sched(2500) == lr0   # tfa triangular, first cycle only
+    model = tf_raft_amd.RAFT(weights=wts, iters=iters, iters_pred=4)
+    with pytest.raises(NotImplementedError):
+        model.compile(optimizer=training.AdamW(wd, sched), clip_norm=clip)
+        model.train_step(batches[0])                                   # the reference's full train_step is not built
+    model.compile(optimizer=training.AdamW(wd, sched), clip_norm=clip, loss=losses.sequence_loss, epe=losses.end_point_error,
+                  trainable='update_block')
+    got_losses = []
+    for step in range(n_steps):
+        res = model.train_step(batches[step])
+        assert set(res) == {'loss', 'epe', 'u1', 'u3', 'u5'}
+        got_losses.append(float(model.flow_metrics['loss'].total))
+    got_losses = [got_losses[0]] + [b - a for a, b in zip(got_losses, got_losses[1:])]
+    want_losses, want_w = _reference_train_steps(wts, batches, iters, sched, wd, clip, n_steps)
+    report('train_step losses', got0=got_losses[0], want0=want_losses[0], got1=got_losses[1], want1=want_losses[1])
+    np.testing.assert_allclose(got_losses, want_losses, rtol=1e-4)
+    new_w = model.get_weights_dict()
+    total, bad, num, den = 0, 0, 0.0, 0.0
+    for k, ref in want_w.items():
+        upd_ref = ref - wts[k].astype(np.float64)
+        upd_got = new_w[k].astype(np.float64) - wts[k].astype(np.float64)
+        total += upd_ref.size
+        bad += int((np.abs(upd_got - upd_ref) > 0.25 * lr0).sum())
+        num += float(((upd_got - upd_ref) ** 2).sum())
+        den += float((upd_ref ** 2).sum())
+        assert np.abs(upd_ref).max() > 0.1 * lr0                      # the reference did move this tensor
+    for k, v in wts.items():
+        if not k.startswith('update_block'):
+            np.testing.assert_array_equal(new_w[k], v)                # frozen encoders
+    report('train_step updated weights', frac_elements_off_by_quarter_lr=bad / total, rel_l2_of_update=float(np.sqrt(num / den)))
+    assert bad / total <= 0.02
+    assert np.sqrt(num / den) <= 0.1
+    # the updated weights are live in the inference kernels
+    out = model([batches[0][0], batches[0][1]])
+    assert len(out) == 4 and np.isfinite(out[-1].numpy()).all()

@@ -686,3 +686,79 @@ extern "C" int raft_upsample_convex_backward_f32(const float *flow, const float 
     upsample_convex_bwd_gather_kernel<<<raft_ceil_div(M, 256), 256, 0, s>>>(workspace, B, h, w, d_flow);
     return raft_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer side of train_step (reference model.py:131-136): tf.clip_by_global_norm + tfa.optimizers.AdamW.
+//   raft_sumsq_f32       sum of squares of a tensor, float64, deterministic (partials per workgroup + ordered final sum);
+//                        accumulate = 1 adds to *out (the global norm runs over all gradient tensors)
+//   raft_adamw_step_f32  tensorflow-addons 0.11.1 DecoupledWeightDecayExtension + Keras Adam (TF 2.3), one tensor:
+//                          var -= weight_decay * var                  (decoupled, NOT scaled by the learning rate)
+//                          g = grad * grad_scale                      (grad_scale = clip_norm / max(global_norm, clip_norm))
+//                          m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2
+//                          var -= lr_t * m / (sqrt(v) + eps),  lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) computed by the caller
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int SUMSQ_WGS = 512;
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const float *__restrict__ x, int64_t n, double *__restrict__ part) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)x[i];
+        acc += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ double sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void sumsq_final_kernel(const double *__restrict__ part, int nparts, int accumulate, double *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = accumulate ? out[0] : 0.0;
+        for (int k = 0; k < nparts; ++k) s += part[k];
+        out[0] = s;
+    }
+}
+__global__ void __launch_bounds__(256) adamw_kernel(float *__restrict__ var, const float *__restrict__ grad, float *__restrict__ m,
+                                                    float *__restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps,
+                                                    float wd, const double *__restrict__ gnorm_sq, float clip_norm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float scale = 1.0f;
+    if (gnorm_sq) {   // tf.clip_by_global_norm: g * clip_norm / max(global_norm, clip_norm)
+        const float gn = (float)sqrt(gnorm_sq[0]);
+        scale = clip_norm / fmaxf(gn, clip_norm);
+    }
+    const float g = grad[i] * scale;
+    float w = var[i];
+    w -= wd * w;
+    const float mi = b1 * m[i] + (1.0f - b1) * g;
+    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    var[i] = w - lr_t * mi / (sqrtf(vi) + eps);
+}
+}   // namespace
+
+extern "C" int64_t raft_sumsq_workspace_doubles(void) { return SUMSQ_WGS; }
+
+extern "C" int raft_sumsq_f32(const float *x, int64_t n, int accumulate, double *out, double *workspace, void *stream) {
+    RAFT_REQUIRE_PTR(x); RAFT_REQUIRE_PTR(out); RAFT_REQUIRE_PTR(workspace);
+    RAFT_REQUIRE(n > 0, RAFT_E_SHAPE);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t g = raft_ceil_div(n, 256);
+    const int grid = (int)(g < SUMSQ_WGS ? g : SUMSQ_WGS);
+    sumsq_partial_kernel<<<grid, 256, 0, s>>>(x, n, workspace);
+    RAFT_TRY(raft_launch_status());
+    sumsq_final_kernel<<<1, 64, 0, s>>>(workspace, grid, accumulate, out);
+    return raft_launch_status();
+}
+
+extern "C" int raft_adamw_step_f32(float *var, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1, float beta2,
+                                   float epsilon, float weight_decay, const double *global_norm_sq, float clip_norm, void *stream) {
+    RAFT_REQUIRE_PTR(var); RAFT_REQUIRE_PTR(grad); RAFT_REQUIRE_PTR(m); RAFT_REQUIRE_PTR(v);
+    RAFT_REQUIRE(n > 0, RAFT_E_SHAPE);
+    adamw_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(var, grad, m, v, n, lr_t, beta1, beta2, epsilon, weight_decay,
+                                                                         global_norm_sq, clip_norm);
+    return raft_launch_status();
+}

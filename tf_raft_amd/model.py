@@ -17,7 +17,9 @@ the current HIP stream with no host synchronisation.  There is no CPU fallback.
 Callers of the forward pass (reference model.py:111-170): ``compile``, ``test_step`` (EPE / u1 / u3 / u5 of the final
 prediction against ground truth, reduced on the device: ``tf_raft_amd.losses``), ``predict_step``, ``reset_metrics``,
 ``load_weights`` / ``save_weights`` (TensorFlow tensor-bundle checkpoints, read and written without TensorFlow) are
-provided.  ``train_step`` (backward pass + optimizer) is out of scope and raises ``NotImplementedError``.
+provided.  ``train_step`` exists for the update block (``compile(..., trainable='update_block')``: backward through time on
+HIP kernels, global-norm clipping, AdamW -- ``tf_raft_amd.grad`` / ``tf_raft_amd.training``); training the encoders is not
+built and the reference's full ``train_step`` therefore still raises ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -84,6 +86,7 @@ class RAFT:
     def set_weights(self, weights: Dict[str, np.ndarray]) -> None:
         weights_mod.check_weights(self.variant, weights)
         self._weights = dict(weights)
+        self._train_vars = None                     # train_step re-reads its device master copies
         self.fnet.set_weights(weights)
         self.cnet.set_weights(weights)
         self.update_block.set_weights(weights)
@@ -290,21 +293,76 @@ class RAFT:
 
 
     # ---- evaluation plumbing (reference model.py:111-170)
-    def compile(self, optimizer=None, clip_norm=None, loss=None, epe=None, **kwargs):
+    def compile(self, optimizer=None, clip_norm=None, loss=None, epe=None, trainable=None, **kwargs):
         """reference model.py:111-124.  ``loss`` / ``epe`` default to ``tf_raft_amd.losses.sequence_loss`` /
-        ``end_point_error``; ``optimizer`` and ``clip_norm`` are kept for the caller but unused (no train_step)."""
+        ``end_point_error``.  ``trainable``: which weights ``train_step`` updates -- only ``'update_block'`` is built so far
+        (encoders frozen; the reference trains everything), ``None`` leaves ``train_step`` unavailable."""
         from . import losses
         if kwargs:
             raise TypeError(f'unexpected keyword arguments {sorted(kwargs)}')
+        if trainable not in (None, 'update_block'):
+            raise ValueError(f"trainable must be None or 'update_block', got {trainable!r}")
         self.optimizer = optimizer
         self.clip_norm = clip_norm
         self.loss = loss if loss is not None else losses.sequence_loss
         self.epe = epe if epe is not None else losses.end_point_error
+        self.trainable = trainable
+        self._train_vars = None
         self.flow_metrics = OrderedDict((k, losses.Mean(name=k)) for k in ('loss', 'epe', 'u1', 'u3', 'u5'))
 
     def train_step(self, data):
-        raise NotImplementedError('train_step (reference model.py:126-144: backward pass, gradient clipping, optimizer) '
-                                  'is outside the MI355X forward-prediction path; use test_step / predict_step')
+        """reference model.py:126-144 restricted to the update block (``compile(..., trainable='update_block')``): forward with
+        ``iters`` iterations (frozen encoders in inference mode, the loop in training form), ``sequence_loss``, backward
+        through time (``tf_raft_amd.grad``), ``clip_by_global_norm`` + the optimizer's ``apply_gradients`` on the device
+        (``tf_raft_amd.training.AdamW``), metrics as the reference.  Every arithmetic step is a HIP kernel; the step is
+        orchestrated from Python and re-packs the updated weights for the inference kernels afterwards -- it is the
+        functional path, not yet a tuned one.  Training the encoders (and with it the reference's full ``train_step``) is
+        not built: without ``trainable='update_block'`` this raises."""
+        from . import grad, losses
+        if not hasattr(self, 'flow_metrics'):
+            raise RuntimeError('call compile() before train_step()')
+        if getattr(self, 'trainable', None) != 'update_block' or self.variant != 'raft':
+            raise NotImplementedError(
+                "train_step (reference model.py:126-144) is built for the update block of RAFT only: "
+                "compile(optimizer, clip_norm, loss, epe, trainable='update_block'); the backward of the encoders and of "
+                'the volume build does not exist yet')
+        if self.loss is not losses.sequence_loss:
+            raise NotImplementedError('train_step differentiates tf_raft_amd.losses.sequence_loss only')
+        if self.optimizer is None or not hasattr(self.optimizer, 'apply_gradients'):
+            raise RuntimeError('compile() needs an optimizer with apply_gradients(grads, variables, clip_norm) '
+                               '(tf_raft_amd.training.AdamW)')
+        image1, image2, flow, valid = data
+        image1 = _dev.to_device(image1)
+        image2 = _dev.to_device(image2)
+        B, H, W, _ = image1.shape
+        if H % 8 or W % 8:
+            raise ValueError(f'H and W must be multiples of 8 (got {H}x{W})')
+        fmap1, fmap2 = self.fnet([image1, image2], training=False, _raw_images=True)
+        correlation = CorrBlock(fmap1, fmap2, num_levels=self.corr_levels, radius=self.corr_radius)
+        cnet = self.cnet(image1, training=False, _raw_images=True)
+        h, w = H // 8, W // 8
+        st = self._get_state(B, h, w, image1.device)
+        check(_dev.lib().raft_prepare_state_f32(_dev.ptr(cnet), st.B, st.h, st.w, C.byref(st.c), _dev.stream_ptr()),
+              'prepare_state')                                             # model.py:84-86: net = tanh(.), inp = relu(.)
+        net0 = st.net.clone()
+        inp = st.x[..., :self.context_dim].contiguous()
+        prefix = 'update_block'
+        ub = {k: v for k, v in self._weights.items() if k.startswith(prefix)}
+        preds, tape = grad.loop_forward(ub, correlation, net0, inp, self.iters, prefix)
+        loss = self.loss([flow, valid], preds)
+        d_preds = grad.sequence_loss_grad((flow, valid), preds)
+        _, _, _, wg = grad.loop_backward(ub, correlation, tape, d_preds, prefix)
+        if self._train_vars is None:
+            self._train_vars = {k: _dev.to_device(np.ascontiguousarray(v)).as_subclass(torch.Tensor).clone() for k, v in ub.items()}
+        self.optimizer.apply_gradients({k: wg[k] for k in self._train_vars}, self._train_vars, clip_norm=self.clip_norm)
+        for k, v in self._train_vars.items():
+            self._weights[k] = v.detach().cpu().numpy()
+        self.update_block.set_weights(self._weights)
+        info = self.epe([flow, valid], preds[-1])
+        self.flow_metrics['loss'].update_state(loss)
+        for k in ('epe', 'u1', 'u3', 'u5'):
+            self.flow_metrics[k].update_state(info[k])
+        return {k: m.result() for k, m in self.flow_metrics.items()}
 
     def test_step(self, data):
         """reference model.py:146-158: forward prediction, then EPE / u1 / u3 / u5 of ``flow_predictions[-1]`` against
