@@ -175,7 +175,7 @@ def test_end_point_error_metric_and_test_step(rng):
     assert out['loss'] == 0.0                      # only train_step feeds it
     model.reset_metrics()
     assert all(m.count == 0 for m in model.flow_metrics.values())
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):       # compile() above did not ask for trainable='update_block'
         model.train_step((None, None, None, None))
 
 
