@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 205          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 206          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -491,6 +491,22 @@ int raft_sumsq_f32(const float *x, int64_t n, int accumulate, double *out, doubl
  * m, v Adam moments; var -= lr_t * m / (sqrt(v) + epsilon) with lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) from the caller. */
 int raft_adamw_step_f32(float *var, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1, float beta2,
                         float epsilon, float weight_decay, const double *global_norm_sq, float clip_norm, void *stream);
+
+/* ---- backward of the volume build and of the state preparation */
+
+/* Generic strided batched GEMM on fp32 MFMA: C[b][m][n] = alpha * sum_k A(b,m,k) B(b,k,n) + beta * C[b][m][n] with
+ * A(b,m,k) = a[b*sab + m*sam + k*sak], B(b,k,n) = b[b*sbb + k*sbk + n*sbn], C row-major (ldc) with batch stride scb. */
+int raft_gemm_f32(const float *a, int64_t sab, int64_t sam, int64_t sak, const float *b, int64_t sbb, int64_t sbk, int64_t sbn,
+                  float *c, int64_t scb, int ldc, int batch, int M, int N, int K, float alpha, float beta, void *stream);
+/* Backward of raft_corr_build_f32 (CorrBlock.__init__, corr.py:100-114, 154-162): d_pyr (layout of the pyramid) ->
+ * d_fmap1, d_fmap2 (B, h, w, C), overwritten.  fmap2_pyr: the pooled-fmap2 workspace the forward filled; workspace: as
+ * many floats again (raft_corr_build_workspace_floats). */
+int raft_corr_build_backward_f32(const float *fmap1, const float *fmap2_pyr, const float *d_pyr, const int64_t *level_offsets,
+                                 int B, int h, int w, int C, int levels, float *d_fmap1, float *d_fmap2, float *workspace,
+                                 void *stream);
+/* model.py:84-86 backward: d_cnet (M, hdim + cdim) = [d_net0 * (1 - net0^2) | d_inp where inp > 0]. */
+int raft_prepare_state_backward_f32(const float *net0, const float *inp, const float *d_net0, const float *d_inp, int hdim,
+                                    int cdim, int64_t M, float *d_cnet, void *stream);
 
 #ifdef __cplusplus
 }

@@ -400,3 +400,52 @@ def test_train_step_update_block_matches_reference_semantics(rng):
     # the updated weights are live in the inference kernels
     out = model([batches[0][0], batches[0][1]])
     assert len(out) == 4 and np.isfinite(out[-1].numpy()).all()
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 12, 64), (1, 9, 13, 32), (1, 46, 62, 256)])
+def test_corr_build_backward_matches_autograd(rng, shape):
+    """Backward of the volume build (reference corr.py:100-114, 154-162: matmul / sqrt(C), three average poolings) for a
+    random upstream gradient on every level of the pyramid.  (1, 46, 62, 256) is the training crop's feature map."""
+    import oracle
+    from tf_raft_amd import grad
+    from tf_raft_amd.layers.corr import CorrBlock, tile_maps
+    B, h, w, C = shape
+    levels = 4 if min(h, w) >= 8 else 3
+    f1 = rng.normal(size=shape).astype(np.float32)
+    f2 = rng.normal(size=shape).astype(np.float32)
+    t1 = torch.tensor(f1, dtype=torch.float64, requires_grad=True)
+    t2 = torch.tensor(f2, dtype=torch.float64, requires_grad=True)
+    ref = oracle.CorrBlock(t1, t2, levels, 4)
+    dev = CorrBlock(f1, f2, levels, 4)
+    ups = [rng.normal(size=tuple(lvl.shape)).astype(np.float32) for lvl in ref.corr_pyramid]
+    torch.autograd.backward(ref.corr_pyramid, [torch.tensor(u, dtype=torch.float64) for u in ups])
+    d_pyr = torch.zeros_like(dev._pyr)
+    for l, u in enumerate(ups):                      # the upstream gradient in the library's tiled layout
+        d_pyr[dev._off[l]:dev._off[l + 1]] = tile_maps(torch.as_tensor(u[..., 0]).to(d_pyr.device)).reshape(-1)
+    d1, d2 = grad.corr_build_backward(dev, d_pyr)
+    for name, got, want in (('d_fmap1', d1, t1.grad), ('d_fmap2', d2, t2.grad)):
+        want = want.numpy()
+        rel = float(np.abs(_np(got) - want).max() / max(1.0, np.abs(want).max()))
+        report(f'corr_build backward {shape} {name}', rel_err=rel, scale=float(np.abs(want).max()))
+        assert rel <= 5e-6
+
+
+def test_gemm_and_state_backward(rng):
+    from tf_raft_amd import _dev, grad
+    from tf_raft_amd._ffi import check
+    # strided batched GEMM: C = 0.5 * A^T B + 2 C0 with ragged sizes
+    Bt, M, N, K = 2, 70, 45, 37
+    a = rng.normal(size=(Bt, K, M)).astype(np.float32)            # A(b, m, k) = a[b, k, m]
+    b = rng.normal(size=(Bt, K, N)).astype(np.float32)
+    c0 = rng.normal(size=(Bt, M, N)).astype(np.float32)
+    a_d, b_d, c_d = _dev.to_device(a), _dev.to_device(b), _dev.to_device(c0.copy())
+    check(_dev.lib().raft_gemm_f32(_dev.ptr(a_d), K * M, 1, M, _dev.ptr(b_d), K * N, N, 1, _dev.ptr(c_d), M * N, N, Bt, M, N, K, 0.5, 2.0,
+                                   _dev.stream_ptr()), 'gemm')
+    want = 0.5 * np.einsum('bkm,bkn->bmn', a.astype(np.float64), b.astype(np.float64)) + 2.0 * c0
+    np.testing.assert_allclose(_np(c_d), want, atol=2e-5)
+    net0 = np.tanh(rng.normal(size=(1, 5, 7, 128))).astype(np.float32)
+    inp = np.maximum(rng.normal(size=(1, 5, 7, 128)), 0).astype(np.float32)
+    dn, di = rng.normal(size=net0.shape).astype(np.float32), rng.normal(size=inp.shape).astype(np.float32)
+    got = _np(grad.prepare_state_backward(net0, inp, dn, di))
+    np.testing.assert_allclose(got[..., :128], dn * (1 - net0 ** 2), rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(got[..., 128:], np.where(inp > 0, di, 0))

@@ -762,3 +762,178 @@ extern "C" int raft_adamw_step_f32(float *var, const float *grad, float *m, floa
                                                                          global_norm_sq, clip_norm);
     return raft_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Generic strided batched GEMM on fp32 MFMA 16x16x4 (training-side plumbing: the backward of the volume build needs
+// NN and TN products of activations):  C[b][m][n] = alpha * sum_k A(b, m, k) * B(b, k, n) + beta * C[b][m][n],
+//   A(b, m, k) = a[b * sab + m * sam + k * sak],  B(b, k, n) = bm[b * sbb + k * sbk + n * sbn],  C row-major with ldc.
+// Workgroup = 64 x 64 output tile, wave w = rows 16 w .. 16 w + 15 x 4 column blocks; 16-deep K chunks staged in LDS
+// through the generic strides (zero fill past the edges).  Correctness-first: ~10-20 TF, enough for a step that runs
+// once per training iteration next to ~300 convolutions.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct GemmArgs {
+    const float *a, *b;
+    float *c;
+    int M, N, K;
+    int64_t sab, sam, sak, sbb, sbk, sbn, scb;
+    int ldc;
+    float alpha, beta;
+};
+
+__global__ void __launch_bounds__(256) gemm_strided_kernel(GemmArgs p) {
+    __shared__ float sA[64][17], sB[16][65];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const float *A = p.a + (int64_t)blockIdx.z * p.sab, *B = p.b + (int64_t)blockIdx.z * p.sbb;
+    float *Cm = p.c + (int64_t)blockIdx.z * p.scb;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            {   // A tile: 64 rows x 16 k; consecutive threads walk the faster-varying of (m, k)
+                const bool kfast = p.sak <= p.sam;
+                const int mm = kfast ? e / 16 : e % 64, kk = kfast ? e % 16 : e / 64;
+                const int m = m0 + mm, k = k0 + kk;
+                sA[mm][kk] = (m < p.M && k < p.K) ? A[m * p.sam + k * p.sak] : 0.f;
+            }
+            {   // B tile: 16 k x 64 cols
+                const bool nfast = p.sbn <= p.sbk;
+                const int kk = nfast ? e / 64 : e % 16, nn = nfast ? e % 64 : e / 16;
+                const int k = k0 + kk, n = n0 + nn;
+                sB[kk][nn] = (k < p.K && n < p.N) ? B[k * p.sbk + n * p.sbn] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float av = sA[wv * 16 + r][q * 4 + g];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sB[q * 4 + g][j * 16 + r], acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wv * 16 + 4 * g + e, n = n0 + j * 16 + r;
+            if (m < p.M && n < p.N) {
+                float *dst = Cm + (int64_t)m * p.ldc + n;
+                *dst = p.alpha * acc[j][e] + (p.beta != 0.f ? p.beta * *dst : 0.f);
+            }
+        }
+}
+
+int launch_gemm(const GemmArgs &a, int batch, hipStream_t s) {
+    const dim3 grid(raft_ceil_div(a.N, 64), raft_ceil_div(a.M, 64), batch);
+    gemm_strided_kernel<<<grid, 256, 0, s>>>(a);
+    return raft_launch_status();
+}
+
+// dF[l-1](child) += 0.25 * dF[l](parent): the adjoint of fmap_pool_kernel (2x2 VALID average over tiled rows)
+__global__ void __launch_bounds__(256) fmap_pool_backward_kernel(float *__restrict__ ws, int64_t tot_rows_per_b, int C, int64_t child_off,
+                                                                 int ch, int cw, int ctx, int64_t parent_off, int ph, int pw, int ptx,
+                                                                 int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int x = (int)(r % cw);
+    r /= cw;
+    const int y = (int)(r % ch);
+    const int64_t b = r / ch;
+    if ((y >> 1) >= ph || (x >> 1) >= pw) return;                       // dropped by the VALID pooling
+    const float g = ws[(b * tot_rows_per_b + parent_off + raft_tiled_index(y >> 1, x >> 1, ptx)) * C + c];
+    ws[(b * tot_rows_per_b + child_off + raft_tiled_index(y, x, ctx)) * C + c] += 0.25f * g;
+}
+
+__global__ void __launch_bounds__(256) fmap_untile_level0_kernel(const float *__restrict__ ws, int64_t tot_rows_per_b, int C, int h, int w,
+                                                                 int tiles_x, float *__restrict__ out, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int x = (int)(r % w);
+    r /= w;
+    const int y = (int)(r % h);
+    const int64_t b = r / h;
+    out[i] = ws[(b * tot_rows_per_b + raft_tiled_index(y, x, tiles_x)) * C + c];
+}
+
+__global__ void __launch_bounds__(256) state_backward_kernel(const float *__restrict__ net0, const float *__restrict__ inp, const float *__restrict__ d_net0,
+                                                             const float *__restrict__ d_inp, int hdim, int cdim, int64_t M,
+                                                             float *__restrict__ d_cnet) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per = hdim + cdim;
+    if (i >= M * per) return;
+    const int64_t m = i / per;
+    const int c = (int)(i - m * per);
+    if (c < hdim) {
+        const float t = net0[m * hdim + c];
+        d_cnet[i] = d_net0[m * hdim + c] * (1.0f - t * t);
+    } else {
+        d_cnet[i] = inp[m * cdim + c - hdim] > 0.f ? d_inp[m * cdim + c - hdim] : 0.f;
+    }
+}
+}   // namespace
+
+extern "C" int raft_gemm_f32(const float *a, int64_t sab, int64_t sam, int64_t sak, const float *b, int64_t sbb, int64_t sbk, int64_t sbn,
+                             float *c, int64_t scb, int ldc, int batch, int M, int N, int K, float alpha, float beta, void *stream) {
+    RAFT_REQUIRE_PTR(a); RAFT_REQUIRE_PTR(b); RAFT_REQUIRE_PTR(c);
+    RAFT_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && ldc >= N, RAFT_E_SHAPE);
+    GemmArgs g = {a, b, c, M, N, K, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, beta};
+    return launch_gemm(g, batch, (hipStream_t)stream);
+}
+
+// Backward of raft_corr_build_f32: level l of the volume is fmap1 . pooled_l(fmap2)^T / sqrt(C), so
+//   d_fmap1 = sum_l dP_l . F2_l / sqrt(C)            (NN products over the level's tiled map columns)
+//   dF2_l   = dP_l^T . fmap1 / sqrt(C)               (TN)
+// followed by the adjoint of the 2x2 average pooling chain (level 3 -> 0) and the un-tiling of level 0.
+extern "C" int raft_corr_build_backward_f32(const float *fmap1, const float *fmap2_pyr, const float *d_pyr, const int64_t *level_offsets,
+                                            int B, int h, int w, int C, int levels, float *d_fmap1, float *d_fmap2, float *workspace,
+                                            void *stream) {
+    RAFT_REQUIRE_PTR(fmap1); RAFT_REQUIRE_PTR(fmap2_pyr); RAFT_REQUIRE_PTR(d_pyr); RAFT_REQUIRE_PTR(level_offsets);
+    RAFT_REQUIRE_PTR(d_fmap1); RAFT_REQUIRE_PTR(d_fmap2); RAFT_REQUIRE_PTR(workspace);
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, RAFT_E_SHAPE);
+    PyramidGeom g;
+    RAFT_TRY(raft_make_geom(h, w, levels, level_offsets, &g));
+    hipStream_t s = (hipStream_t)stream;
+    const int N = h * w;
+    int64_t col_off[RAFT_MAX_LEVELS + 1], T = 0;
+    for (int l = 0; l < levels; ++l) {
+        col_off[l] = T;
+        T += g.map[l];
+    }
+    const float rs = 1.0f / sqrtf((float)C);
+    for (int l = 0; l < levels; ++l) {
+        const int K = g.map[l];
+        GemmArgs a1 = {d_pyr + g.off[l], fmap2_pyr + col_off[l] * C, d_fmap1, N, C, K,
+                       (int64_t)N * K, K, 1, T * C, C, 1, (int64_t)N * C, C, rs, l ? 1.0f : 0.0f};
+        RAFT_TRY(launch_gemm(a1, B, s));
+        GemmArgs a2 = {d_pyr + g.off[l], fmap1, workspace + col_off[l] * C, K, C, N,
+                       (int64_t)N * K, 1, K, (int64_t)N * C, C, 1, T * C, C, rs, 0.0f};
+        RAFT_TRY(launch_gemm(a2, B, s));
+    }
+    for (int l = levels - 1; l >= 1; --l) {
+        const int64_t total = (int64_t)B * g.lh[l - 1] * g.lw[l - 1] * C;
+        fmap_pool_backward_kernel<<<raft_ceil_div(total, 256), 256, 0, s>>>(workspace, T, C, col_off[l - 1], g.lh[l - 1], g.lw[l - 1],
+                                                                            g.tx[l - 1], col_off[l], g.lh[l], g.lw[l], g.tx[l], total);
+        RAFT_TRY(raft_launch_status());
+    }
+    const int64_t total = (int64_t)B * N * C;
+    fmap_untile_level0_kernel<<<raft_ceil_div(total, 256), 256, 0, s>>>(workspace, T, C, h, w, g.tx[0], d_fmap2, total);
+    return raft_launch_status();
+}
+
+// model.py:84-86 backward: d cnet = [d_net0 * (1 - net0^2) | d_inp * (inp > 0)]
+extern "C" int raft_prepare_state_backward_f32(const float *net0, const float *inp, const float *d_net0, const float *d_inp, int hdim,
+                                               int cdim, int64_t M, float *d_cnet, void *stream) {
+    RAFT_REQUIRE_PTR(net0); RAFT_REQUIRE_PTR(inp); RAFT_REQUIRE_PTR(d_net0); RAFT_REQUIRE_PTR(d_inp); RAFT_REQUIRE_PTR(d_cnet);
+    RAFT_REQUIRE(hdim > 0 && cdim > 0 && M > 0, RAFT_E_SHAPE);
+    state_backward_kernel<<<raft_ceil_div(M * (hdim + cdim), 256), 256, 0, (hipStream_t)stream>>>(net0, inp, d_net0, d_inp, hdim, cdim, M, d_cnet);
+    return raft_launch_status();
+}

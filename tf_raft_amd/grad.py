@@ -352,3 +352,34 @@ def loop_backward(weights, corr_block, tape, d_preds, prefix='update_block'):
         else:
             wg = {k: _axpby(1.0, wg[k], 1.0, v.as_subclass(torch.Tensor).contiguous()) for k, v in dw.items()}
     return _dev.wrap(d_net), _dev.wrap(d_inp), d_pyr, {k: _dev.wrap(v) for k, v in wg.items()}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# fourth slice: from the loop back to the encoder outputs
+# ------------------------------------------------------------------------------------------------------------------------
+
+def corr_build_backward(corr_block, d_pyramid):
+    """Backward of ``CorrBlock(fmap1, fmap2)`` (reference corr.py:100-114, 154-162): the gradient w.r.t. the stored pyramid
+    (flat, tiled layout -- what ``corr_lookup_backward`` / ``loop_backward`` accumulate) -> ``(d_fmap1, d_fmap2)``."""
+    if corr_block._pyr is None:
+        raise ValueError('the on-demand CorrBlock stores no pyramid to differentiate')
+    f1 = corr_block.fmap1.as_subclass(torch.Tensor)
+    bs, h, w, c = f1.shape
+    d_pyr = _f32(d_pyramid)
+    d1, d2 = torch.empty_like(f1), torch.empty_like(f1)
+    ws = torch.empty_like(corr_block._f2pyr)
+    check(_dev.lib().raft_corr_build_backward_f32(_dev.ptr(f1), _dev.ptr(corr_block._f2pyr), _dev.ptr(d_pyr), corr_block._off, bs, h, w, c,
+                                                  corr_block.num_levels, _dev.ptr(d1), _dev.ptr(d2), _dev.ptr(ws), _dev.stream_ptr()),
+          'corr_build_backward')
+    return _dev.wrap(d1), _dev.wrap(d2)
+
+
+def prepare_state_backward(net0, inp, d_net0, d_inp):
+    """Backward of ``net = tanh(cnet[..., :hdim]); inp = relu(cnet[..., hdim:])`` (reference model.py:84-86): ``d_cnet``."""
+    net0, inp, d_net0, d_inp = (_f32(t) for t in (net0, inp, d_net0, d_inp))
+    hdim, cdim = net0.shape[-1], inp.shape[-1]
+    M = net0.numel() // hdim
+    out = torch.empty(tuple(net0.shape[:-1]) + (hdim + cdim,), device=net0.device, dtype=torch.float32)
+    check(_dev.lib().raft_prepare_state_backward_f32(_dev.ptr(net0), _dev.ptr(inp), _dev.ptr(d_net0), _dev.ptr(d_inp), hdim, cdim, M,
+                                                     _dev.ptr(out), _dev.stream_ptr()), 'prepare_state_backward')
+    return _dev.wrap(out)
