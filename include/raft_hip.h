@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 206          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 207          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -507,6 +507,21 @@ int raft_corr_build_backward_f32(const float *fmap1, const float *fmap2_pyr, con
 /* model.py:84-86 backward: d_cnet (M, hdim + cdim) = [d_net0 * (1 - net0^2) | d_inp where inp > 0]. */
 int raft_prepare_state_backward_f32(const float *net0, const float *inp, const float *d_net0, const float *d_inp, int hdim,
                                     int cdim, int64_t M, float *d_cnet, void *stream);
+
+/* ---- normalisation layers of the encoders in training form (extractor.py:6-16) */
+
+/* x viewed as (G groups, P pixels, C channels): tfa InstanceNormalization = (G = B, P = H*W), Keras BatchNormalization with
+ * batch statistics = (G = 1, P = B*H*W); biased variance, y = (x - mean) * rstd * gamma + beta [relu], rstd = 1/sqrt(var + eps).
+ * mean, rstd (and var when non-NULL): (G, C), kept for the backward / the moving statistics.  Deterministic float64 sums.
+ * workspace: raft_norm_workspace_doubles(G, C) doubles. */
+int64_t raft_norm_workspace_doubles(int G, int C);
+int raft_norm_forward_f32(const float *x, int G, int64_t P, int C, const float *gamma, const float *beta, float eps, int relu,
+                          float *y, float *mean, float *rstd, float *var, double *workspace, void *stream);
+/* dy is the gradient at the norm's linear output (apply raft_relu_backward_f32 first when relu was fused). */
+int raft_norm_backward_f32(const float *x, const float *dy, const float *mean, const float *rstd, const float *gamma, int G,
+                           int64_t P, int C, float *dx, float *dgamma, float *dbeta, double *workspace, void *stream);
+/* out = relu(alpha * a + beta * b): the residual join of a ResBlock (extractor.py:49). */
+int raft_axpby_relu_f32(float alpha, const float *a, float beta, const float *b, float *out, int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -449,3 +449,42 @@ def test_gemm_and_state_backward(rng):
     got = _np(grad.prepare_state_backward(net0, inp, dn, di))
     np.testing.assert_allclose(got[..., :128], dn * (1 - net0 ** 2), rtol=1e-6, atol=1e-7)
     np.testing.assert_array_equal(got[..., 128:], np.where(inp > 0, di, 0))
+
+
+@pytest.mark.parametrize('prefix,variant', [('fnet', 'raft'), ('cnet', 'raft'), ('cnet', 'small')])
+def test_encoder_backward_matches_autograd(rng, prefix, variant):
+    """Fifth slice: the encoders in training form (reference extractor.py:6-49, 88-175): fnet = instance norm over the two
+    frames batched together, RAFT cnet = batch norm with BATCH statistics (training=True), SmallRAFT cnet = no norm.
+    Forward against the float64 oracle, then the gradient of a random upstream w.r.t. every kernel, bias, gamma, beta
+    against autograd."""
+    from oracle.layers import W, encoder
+    from tf_raft_amd import grad
+    from tf_raft_amd import weights as wm
+    B, H, Wd = 2, 64, 96
+    wts = {k: v for k, v in wm.init_weights(variant, seed=9, perturb=True).items() if k.startswith(prefix + '/')}
+    x = (2 * rng.uniform(0, 1, (B, H, Wd, 3)) - 1).astype(np.float32)
+    ow = W(wts, torch.float64)
+    for k, t in ow.t.items():
+        if 'moving' not in k:
+            t.requires_grad_(True)
+    ref = encoder(ow, prefix, torch.tensor(x, dtype=torch.float64), training=True)
+    got, tape = grad.encoder_forward(wts, prefix, x, training=True)
+    err = float(np.abs(_np(got) - ref.detach().numpy()).max())
+    report(f'encoder training forward {variant} {prefix}', max_abs_vs_f64=err, scale=float(ref.abs().max()))
+    assert err <= 1e-4 * max(1.0, float(ref.abs().max()))
+    d_out = rng.normal(size=tuple(ref.shape)).astype(np.float32)
+    ref.backward(torch.tensor(d_out, dtype=torch.float64))
+    g, stats = grad.encoder_backward(wts, prefix, tape, d_out)
+    names = sorted(k for k in wts if 'moving' not in k)
+    assert sorted(g) == names
+    worst = 0.0
+    for k in names:
+        want = ow.t[k].grad.numpy()
+        diff = _np(g[k]).astype(np.float64) - want
+        rel2 = float(np.linalg.norm(diff) / max(np.linalg.norm(want), 1e-30))
+        worst = max(worst, rel2)
+        assert _np(g[k]).shape == want.shape, k
+        assert rel2 <= 2e-3, (k, rel2)
+    report(f'encoder backward {variant} {prefix}', worst_rel_l2_over_all_parameters=worst, n_parameters=len(names),
+           batch_norm_layers=len(stats))
+    assert (len(stats) > 0) == (variant == 'raft' and prefix == 'cnet')

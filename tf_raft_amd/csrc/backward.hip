@@ -937,3 +937,165 @@ extern "C" int raft_prepare_state_backward_f32(const float *net0, const float *i
     state_backward_kernel<<<raft_ceil_div(M * (hdim + cdim), 256), 256, 0, (hipStream_t)stream>>>(net0, inp, d_net0, d_inp, hdim, cdim, M, d_cnet);
     return raft_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Normalisation layers of the encoders in TRAINING form (reference extractor.py:6-16): tfa InstanceNormalization
+// (per sample and channel over H x W) and Keras BatchNormalization with batch statistics (per channel over B x H x W),
+// both eps = 1e-3 and biased variance.  x is viewed as (G groups, P pixels, C channels): G = B, P = H*W for instance
+// norm; G = 1, P = B*H*W for batch norm.
+//   stats     mean[g][c], rstd[g][c] = 1 / sqrt(var + eps)            (float64 partial sums over pixel slices, ordered)
+//   apply     y = (x - mean) * rstd * gamma + beta   [+ relu]
+//   backward  dx = gamma rstd (dy - mean_P(dy) - xhat mean_P(dy xhat)),  dgamma[c] = sum dy xhat,  dbeta[c] = sum dy
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int NORM_SLICES = 64;
+
+// part[(g * NORM_SLICES + s) * C + c] = {sum a, sum b} over the slice's pixels; mode 0: (x, x^2); mode 1: (dy, dy * xhat)
+__global__ void __launch_bounds__(256) norm_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mean,
+                                                           const float *__restrict__ rstd, int64_t P, int C, int mode,
+                                                           double2 *__restrict__ part) {
+    __shared__ double2 sh[4][64];
+    const int g = blockIdx.x / NORM_SLICES, s = blockIdx.x % NORM_SLICES;
+    const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
+    const int64_t lo = P * s / NORM_SLICES, hi = P * (s + 1) / NORM_SLICES;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + cl;
+        double a = 0.0, b = 0.0;
+        if (c < C) {
+            const float mu = mode ? mean[(int64_t)g * C + c] : 0.f, rs = mode ? rstd[(int64_t)g * C + c] : 0.f;
+            for (int64_t p = lo + pr; p < hi; p += 4) {
+                const int64_t i = ((int64_t)g * P + p) * C + c;
+                if (mode == 0) {
+                    const double v = (double)x[i];
+                    a += v;
+                    b += v * v;
+                } else {
+                    const float d = dy[i];
+                    a += (double)d;
+                    b += (double)(d * ((x[i] - mu) * rs));
+                }
+            }
+        }
+        sh[pr][cl] = make_double2(a, b);
+        __syncthreads();
+        if (pr == 0 && c < C) {
+            const double2 t0 = sh[0][cl], t1 = sh[1][cl], t2 = sh[2][cl], t3 = sh[3][cl];
+            part[((int64_t)g * NORM_SLICES + s) * C + c] = make_double2((t0.x + t1.x) + (t2.x + t3.x), (t0.y + t1.y) + (t2.y + t3.y));
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) norm_stats_final_kernel(const double2 *__restrict__ part, int G, int C, double inv_count, float eps,
+                                                               float *__restrict__ mean, float *__restrict__ rstd, float *__restrict__ var_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < NORM_SLICES; ++s) {
+        const double2 t = part[((int64_t)g * NORM_SLICES + s) * C + c];
+        a += t.x;
+        b += t.y;
+    }
+    const double mu = a * inv_count;
+    double var = b * inv_count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)mu;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (var_out) var_out[i] = (float)var;
+}
+
+__global__ void __launch_bounds__(256) norm_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta, int64_t P, int C,
+                                                         int relu, int64_t total, float *__restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int64_t g = i / ((int64_t)P * C);
+    float v = (x[i] - mean[g * C + c]) * rstd[g * C + c] * gamma[c] + beta[c];
+    y[i] = relu ? fmaxf(v, 0.f) : v;
+}
+
+// sums[(g * C + c)] = {sum dy, sum dy xhat} over the group (ordered over slices); dgamma / dbeta over the groups
+__global__ void __launch_bounds__(256) norm_bwd_final_kernel(const double2 *__restrict__ part, int G, int C, double2 *__restrict__ sums,
+                                                             float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double tg = 0.0, tb = 0.0;
+    for (int g = 0; g < G; ++g) {
+        double a = 0.0, b = 0.0;
+        for (int s = 0; s < NORM_SLICES; ++s) {
+            const double2 t = part[((int64_t)g * NORM_SLICES + s) * C + c];
+            a += t.x;
+            b += t.y;
+        }
+        sums[(int64_t)g * C + c] = make_double2(a, b);
+        tb += a;
+        tg += b;
+    }
+    dgamma[c] = (float)tg;
+    dbeta[c] = (float)tb;
+}
+
+__global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mean,
+                                                          const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                          const double2 *__restrict__ sums, int64_t P, int C, double inv_count, int64_t total,
+                                                          float *__restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int64_t g = i / ((int64_t)P * C);
+    const float rs = rstd[g * C + c], xh = (x[i] - mean[g * C + c]) * rs;
+    const double2 t = sums[g * C + c];
+    dx[i] = gamma[c] * rs * (dy[i] - (float)(t.x * inv_count) - xh * (float)(t.y * inv_count));
+}
+}   // namespace
+
+extern "C" int64_t raft_norm_workspace_doubles(int G, int C) { return (G > 0 && C > 0) ? (int64_t)2 * (NORM_SLICES + 1) * G * C : 0; }
+
+extern "C" int raft_norm_forward_f32(const float *x, int G, int64_t P, int C, const float *gamma, const float *beta, float eps, int relu,
+                                     float *y, float *mean, float *rstd, float *var, double *workspace, void *stream) {
+    RAFT_REQUIRE_PTR(x); RAFT_REQUIRE_PTR(gamma); RAFT_REQUIRE_PTR(beta); RAFT_REQUIRE_PTR(y);
+    RAFT_REQUIRE_PTR(mean); RAFT_REQUIRE_PTR(rstd); RAFT_REQUIRE_PTR(workspace);
+    RAFT_REQUIRE(G > 0 && P > 0 && C > 0, RAFT_E_SHAPE);
+    hipStream_t s = (hipStream_t)stream;
+    norm_partial_kernel<<<G * NORM_SLICES, 256, 0, s>>>(x, nullptr, nullptr, nullptr, P, C, 0, (double2 *)workspace);
+    RAFT_TRY(raft_launch_status());
+    norm_stats_final_kernel<<<raft_ceil_div((int64_t)G * C, 256), 256, 0, s>>>((const double2 *)workspace, G, C, 1.0 / (double)P, eps, mean, rstd, var);
+    RAFT_TRY(raft_launch_status());
+    const int64_t total = (int64_t)G * P * C;
+    norm_apply_kernel<<<raft_ceil_div(total, 256), 256, 0, s>>>(x, mean, rstd, gamma, beta, P, C, relu, total, y);
+    return raft_launch_status();
+}
+
+extern "C" int raft_norm_backward_f32(const float *x, const float *dy, const float *mean, const float *rstd, const float *gamma, int G,
+                                      int64_t P, int C, float *dx, float *dgamma, float *dbeta, double *workspace, void *stream) {
+    RAFT_REQUIRE_PTR(x); RAFT_REQUIRE_PTR(dy); RAFT_REQUIRE_PTR(mean); RAFT_REQUIRE_PTR(rstd); RAFT_REQUIRE_PTR(gamma);
+    RAFT_REQUIRE_PTR(dx); RAFT_REQUIRE_PTR(dgamma); RAFT_REQUIRE_PTR(dbeta); RAFT_REQUIRE_PTR(workspace);
+    RAFT_REQUIRE(G > 0 && P > 0 && C > 0, RAFT_E_SHAPE);
+    hipStream_t s = (hipStream_t)stream;
+    double2 *part = (double2 *)workspace, *sums = part + (int64_t)NORM_SLICES * G * C;
+    norm_partial_kernel<<<G * NORM_SLICES, 256, 0, s>>>(x, dy, mean, rstd, P, C, 1, part);
+    RAFT_TRY(raft_launch_status());
+    norm_bwd_final_kernel<<<raft_ceil_div(C, 256), 256, 0, s>>>(part, G, C, sums, dgamma, dbeta);
+    RAFT_TRY(raft_launch_status());
+    const int64_t total = (int64_t)G * P * C;
+    norm_bwd_dx_kernel<<<raft_ceil_div(total, 256), 256, 0, s>>>(x, dy, mean, rstd, gamma, sums, P, C, 1.0 / (double)P, total, dx);
+    return raft_launch_status();
+}
+
+// out = [relu](alpha a + beta b): the residual join of a ResBlock (extractor.py:49)
+extern "C" int raft_axpby_relu_f32(float alpha, const float *a, float beta, const float *b, float *out, int64_t n, void *stream);
+namespace {
+__global__ void __launch_bounds__(256) axpby_relu_kernel(float alpha, const float *__restrict__ a, float beta, const float *__restrict__ b,
+                                                         float *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = fmaxf(alpha * a[i] + (b ? beta * b[i] : 0.f), 0.f);
+}
+}   // namespace
+extern "C" int raft_axpby_relu_f32(float alpha, const float *a, float beta, const float *b, float *out, int64_t n, void *stream) {
+    RAFT_REQUIRE_PTR(a); RAFT_REQUIRE_PTR(out);
+    RAFT_REQUIRE(n > 0, RAFT_E_SHAPE);
+    axpby_relu_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(alpha, a, beta, b, out, n);
+    return raft_launch_status();
+}

@@ -383,3 +383,195 @@ def prepare_state_backward(net0, inp, d_net0, d_inp):
     check(_dev.lib().raft_prepare_state_backward_f32(_dev.ptr(net0), _dev.ptr(inp), _dev.ptr(d_net0), _dev.ptr(d_inp), hdim, cdim, M,
                                                      _dev.ptr(out), _dev.stream_ptr()), 'prepare_state_backward')
     return _dev.wrap(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# fifth slice: the encoders in training form (reference extractor.py:6-49, 88-130) and their backward
+# ------------------------------------------------------------------------------------------------------------------------
+# Strided convolutions reuse the stride-1 kernels: a stride-2 'same' convolution is the stride-1 'same' convolution sampled
+# at every second position (TensorFlow's asymmetric SAME padding decides which parity), so its backward is the stride-1
+# backward of the zero-stuffed upstream gradient; the 1x1 stride-2 'valid' projection subsamples its input first; the 7x7
+# stride-2 stem (3 input channels) is a 1x1 convolution over the im2col'ed image.  torch only moves data here (slicing,
+# unfold, zero-stuffing, concatenation); every multiply-add is a HIP kernel.  4x wasted work on three layers per encoder is
+# the price of a functional path without new convolution kernels.
+
+def _same_pad_before(n, k, stride):
+    out = -(-n // stride)
+    total = max((out - 1) * stride + k - n, 0)
+    return out, total // 2
+
+
+def _sub_index(n, k, stride):
+    """Positions of a stride-`stride` SAME convolution's outputs inside the stride-1 SAME output: (start, count)."""
+    out, pb = _same_pad_before(n, k, stride)
+    return (k - 1) // 2 - pb, out
+
+
+def _norm_fwd(x, gamma, beta, per_sample, relu):
+    lib = _dev.lib()
+    B, H, W, C_ = x.shape
+    G, P = (B, H * W) if per_sample else (1, B * H * W)
+    g_d, b_d = _dev.to_device(np.asarray(gamma, np.float32)), _dev.to_device(np.asarray(beta, np.float32))
+    y = torch.empty_like(x)
+    mean, rstd, var = (torch.empty((G, C_), device=x.device, dtype=torch.float32) for _ in range(3))
+    ws = torch.empty((int(lib.raft_norm_workspace_doubles(G, C_)),), device=x.device, dtype=torch.float64)
+    check(lib.raft_norm_forward_f32(_dev.ptr(x), G, P, C_, _dev.ptr(g_d), _dev.ptr(b_d), 1e-3, 1 if relu else 0, _dev.ptr(y), _dev.ptr(mean),
+                                    _dev.ptr(rstd), _dev.ptr(var), _dev.ptr(ws), _dev.stream_ptr()), 'norm_forward')
+    return y, dict(x=x, y=y, mean=mean, rstd=rstd, var=var, gamma=g_d, G=G, P=P, relu=relu)
+
+
+def _norm_bwd(cache, dy):
+    lib = _dev.lib()
+    x = cache['x']
+    C_ = x.shape[-1]
+    dy = dy.contiguous()
+    if cache['relu']:
+        masked = torch.empty_like(dy)
+        check(lib.raft_relu_backward_f32(_dev.ptr(cache['y']), _dev.ptr(dy), _dev.ptr(masked), dy.numel(), _dev.stream_ptr()), 'relu_backward')
+        dy = masked
+    dx = torch.empty_like(x)
+    dg, db = torch.empty((C_,), device=x.device, dtype=torch.float32), torch.empty((C_,), device=x.device, dtype=torch.float32)
+    ws = torch.empty((int(lib.raft_norm_workspace_doubles(cache['G'], C_)),), device=x.device, dtype=torch.float64)
+    check(lib.raft_norm_backward_f32(_dev.ptr(x), _dev.ptr(dy), _dev.ptr(cache['mean']), _dev.ptr(cache['rstd']), _dev.ptr(cache['gamma']),
+                                     cache['G'], cache['P'], C_, _dev.ptr(dx), _dev.ptr(dg), _dev.ptr(db), _dev.ptr(ws), _dev.stream_ptr()),
+          'norm_backward')
+    return dx, dg, db
+
+
+def _relu_bwd(y, dy):
+    out = torch.empty_like(dy)
+    check(_dev.lib().raft_relu_backward_f32(_dev.ptr(y), _dev.ptr(dy.contiguous()), _dev.ptr(out), dy.numel(), _dev.stream_ptr()), 'relu_backward')
+    return out
+
+
+def _conv_s(x, kernel, bias, stride):
+    """Keras Conv2D(k, stride, 'same') for k in {3} and stride in {1, 2} through the stride-1 kernel (see above)."""
+    y1 = _conv_fwd(x, kernel, bias)
+    if stride == 1:
+        return y1, None
+    kh, kw = kernel.shape[:2]
+    sy, ny = _sub_index(x.shape[1], kh, stride)
+    sx, nx = _sub_index(x.shape[2], kw, stride)
+    return y1[:, sy::stride, sx::stride][:, :ny, :nx].contiguous(), (sy, sx, tuple(y1.shape))
+
+
+def _conv_s_bwd(x, kernel, dy, sub, stride):
+    if sub is not None:
+        sy, sx, full = sub
+        dy1 = torch.zeros(full, device=dy.device, dtype=torch.float32)
+        dy1[:, sy::stride, sx::stride][:, :dy.shape[1], :dy.shape[2]] = dy
+        dy = dy1
+    return _conv_bwd(x, kernel, dy.contiguous())
+
+
+def _stem_cols(x):
+    """im2col of the 7x7 / stride-2 'same' stem over a (B, H, W, 3) image: (B, Ho, Wo, 147) with depth order (ci, ky, kx)."""
+    B, H, W, _ = x.shape
+    ho, pt = _same_pad_before(H, 7, 2)
+    wo, pl = _same_pad_before(W, 7, 2)
+    pb, pr = max((ho - 1) * 2 + 7 - H, 0) - pt, max((wo - 1) * 2 + 7 - W, 0) - pl
+    xc = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    cols = torch.nn.functional.unfold(xc, 7, stride=2)                     # (B, 3 * 49, Ho * Wo): pure gather
+    return cols.transpose(1, 2).reshape(B, ho, wo, 147).contiguous()
+
+
+def encoder_forward(weights, prefix, x, training=True):
+    """``BasicEncoder`` / ``SmallEncoder`` forward (reference extractor.py:113-130 / 158-175) in training form: ``x`` is the
+    normalised image batch (B, H, W, 3) (the two frames concatenated along the batch for fnet, extractor.py:116).  Batch
+    normalisation uses batch statistics when ``training`` (Keras), instance normalisation is the same in both modes.
+    Returns ``(out, tape)``."""
+    p = prefix
+    w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p + '/')}
+    x = _f32(x)
+    tape = {'layers': []}
+
+    def norm(name, t, relu):
+        if f'{p}/{name}/moving_mean' in w:
+            if training:
+                return _norm_fwd(t, w[f'{p}/{name}/gamma'], w[f'{p}/{name}/beta'], False, relu)
+            # inference statistics: an affine map per channel, expressed through the same kernel with fixed moments
+            raise NotImplementedError('encoder_forward(training=False) with batch norm: use the inference encoders')
+        if f'{p}/{name}/gamma' in w:
+            return _norm_fwd(t, w[f'{p}/{name}/gamma'], w[f'{p}/{name}/beta'], True, relu)
+        if relu:
+            y = torch.empty_like(t)
+            check(_dev.lib().raft_axpby_relu_f32(1.0, _dev.ptr(t), 0.0, None, _dev.ptr(y), t.numel(), _dev.stream_ptr()), 'relu')
+            return y, dict(identity=True, y=y, relu=True)
+        return t, dict(identity=True, y=t, relu=False)
+
+    k1 = w[f'{p}/conv1/kernel']                                             # (7, 7, 3, c0): stem as a 1x1 conv over im2col
+    cols = _stem_cols(x)
+    kcol = np.ascontiguousarray(k1.transpose(2, 0, 1, 3).reshape(1, 1, 147, k1.shape[3]))
+    c = _conv_fwd(cols, kcol, w[f'{p}/conv1/bias'])
+    y, nc = norm('norm1', c, True)
+    tape['stem'] = dict(cols=cols, kcol=kcol, norm=nc)
+    for li, stride in ((1, 1), (2, 2), (3, 2)):
+        for bi, s in ((0, stride), (1, 1)):
+            q = f'layer{li}/{bi}'
+            c1, sub1 = _conv_s(y, w[f'{p}/{q}/conv1/kernel'], w[f'{p}/{q}/conv1/bias'], s)
+            n1, nc1 = norm(f'{q}/norm1', c1, True)
+            c2 = _conv_fwd(n1, w[f'{p}/{q}/conv2/kernel'], w[f'{p}/{q}/conv2/bias'])
+            n2, nc2 = norm(f'{q}/norm2', c2, True)
+            rec = dict(q=q, x=y, stride=s, sub1=sub1, nc1=nc1, n1=n1, nc2=nc2)
+            xs = y
+            if s != 1:
+                xsub = y[:, ::s, ::s].contiguous()
+                d = _conv_fwd(xsub, w[f'{p}/{q}/downsample/0/kernel'], w[f'{p}/{q}/downsample/0/bias'])
+                xs, ncd = norm(f'{q}/downsample/1', d, False)
+                rec.update(xsub=xsub, ncd=ncd)
+            out = torch.empty_like(n2)
+            check(_dev.lib().raft_axpby_relu_f32(1.0, _dev.ptr(xs.contiguous()), 1.0, _dev.ptr(n2), _dev.ptr(out), out.numel(), _dev.stream_ptr()),
+                  'resblock join')
+            rec['out'] = out
+            tape['layers'].append(rec)
+            y = out
+    tape['last'] = y
+    out = _conv_fwd(y, w[f'{p}/conv2/kernel'], w[f'{p}/conv2/bias'])
+    return _dev.wrap(out), tape
+
+
+def encoder_backward(weights, prefix, tape, d_out):
+    """Backward of ``encoder_forward``: gradient w.r.t. every kernel, bias, gamma and beta of the encoder (dict under the
+    weight names; the input image receives none).  Also returns the batch statistics of every batch-norm layer
+    (``{name: (mean, biased variance)}``) for the moving-average update."""
+    p = prefix
+    w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p + '/')}
+    g, stats = {}, {}
+
+    def norm_b(name, cache, dy):
+        if cache.get('identity'):
+            return _relu_bwd(cache['y'], dy) if cache['relu'] else dy
+        dx, dg, db = _norm_bwd(cache, dy)
+        g[f'{p}/{name}/gamma'], g[f'{p}/{name}/beta'] = dg, db
+        if f'{p}/{name}/moving_mean' in w:
+            stats[f'{p}/{name}'] = (cache['mean'][0], cache['var'][0])
+        return dx
+
+    dy = _f32(d_out)
+    dy, dk, db = _conv_bwd(tape['last'], w[f'{p}/conv2/kernel'], dy)
+    g[f'{p}/conv2/kernel'], g[f'{p}/conv2/bias'] = dk, db
+    for rec in reversed(tape['layers']):
+        q, s = rec['q'], rec['stride']
+        m = _relu_bwd(rec['out'], dy)                                       # relu(x + fx): both branches receive m
+        d_c2 = norm_b(f'{q}/norm2', rec['nc2'], m)
+        d_n1, dk, db = _conv_bwd(rec['n1'], w[f'{p}/{q}/conv2/kernel'], d_c2)
+        g[f'{p}/{q}/conv2/kernel'], g[f'{p}/{q}/conv2/bias'] = dk, db
+        d_c1 = norm_b(f'{q}/norm1', rec['nc1'], d_n1)
+        d_x, dk, db = _conv_s_bwd(rec['x'], w[f'{p}/{q}/conv1/kernel'], d_c1, rec['sub1'], s)
+        g[f'{p}/{q}/conv1/kernel'], g[f'{p}/{q}/conv1/bias'] = dk, db
+        if s != 1:
+            d_d = norm_b(f'{q}/downsample/1', rec['ncd'], m)
+            d_xsub, dk, db = _conv_bwd(rec['xsub'], w[f'{p}/{q}/downsample/0/kernel'], d_d)
+            g[f'{p}/{q}/downsample/0/kernel'], g[f'{p}/{q}/downsample/0/bias'] = dk, db
+            skip = torch.zeros_like(d_x)
+            skip[:, ::s, ::s] = d_xsub
+        else:
+            skip = m
+        dy = _axpby(1.0, d_x.contiguous(), 1.0, skip.contiguous())
+    st = tape['stem']
+    d_c = norm_b('norm1', st['norm'], dy)
+    _, dk, db = _conv_bwd(st['cols'], st['kcol'], d_c)
+    c0 = dk.shape[-1]
+    g[f'{p}/conv1/kernel'] = dk.reshape(3, 7, 7, c0).permute(1, 2, 0, 3).contiguous()      # (ci, ky, kx, co) -> Keras (ky, kx, ci, co)
+    g[f'{p}/conv1/bias'] = db
+    return {k: _dev.wrap(v) for k, v in g.items()}, stats
