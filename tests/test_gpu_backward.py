@@ -367,9 +367,8 @@ def test_train_step_update_block_matches_reference_semantics(rng):
     sched = training.CyclicalLearningRate(lr0, 2 * lr0, step_size=1000, scale_fn=training.first_cycle_scaler, scale_mode='cycle')
     assert sched(0) == lr0 and abs(sched(1000) - 2 * lr0) < 1e-12 and sched(2000) == lr0 and sched(2500) == lr0   # tfa triangular, first cycle only
     model = tf_raft_amd.RAFT(weights=wts, iters=iters, iters_pred=4)
-    with pytest.raises(NotImplementedError):
-        model.compile(optimizer=training.AdamW(wd, sched), clip_norm=clip)
-        model.train_step(batches[0])                                   # the reference's full train_step is not built
+    with pytest.raises(ValueError):
+        model.compile(optimizer=training.AdamW(wd, sched), clip_norm=clip, trainable='encoders')
     model.compile(optimizer=training.AdamW(wd, sched), clip_norm=clip, loss=losses.sequence_loss, epe=losses.end_point_error,
                   trainable='update_block')
     got_losses = []
@@ -481,10 +480,81 @@ def test_encoder_backward_matches_autograd(rng, prefix, variant):
     for k in names:
         want = ow.t[k].grad.numpy()
         diff = _np(g[k]).astype(np.float64) - want
-        rel2 = float(np.linalg.norm(diff) / max(np.linalg.norm(want), 1e-30))
-        worst = max(worst, rel2)
         assert _np(g[k]).shape == want.shape, k
+        if np.linalg.norm(want) < 1e-9 * np.sqrt(want.size):
+            # a bias in front of a normalisation layer: the norm removes it, its true gradient is exactly zero (autograd
+            # returns ~1e-17); the fp32 sums leave rounding noise
+            assert np.abs(diff).max() <= 5e-3, (k, float(np.abs(diff).max()))     # ~1e-7 of the sum of |terms|
+            continue
+        rel2 = float(np.linalg.norm(diff) / np.linalg.norm(want))
+        worst = max(worst, rel2)
         assert rel2 <= 2e-3, (k, rel2)
     report(f'encoder backward {variant} {prefix}', worst_rel_l2_over_all_parameters=worst, n_parameters=len(names),
            batch_norm_layers=len(stats))
     assert (len(stats) > 0) == (variant == 'raft' and prefix == 'cnet')
+
+
+def test_full_train_step_matches_reference_semantics(rng):
+    """RAFT.train_step as the reference defines it (model.py:126-144): ALL weights trainable, forward in training mode
+    (cnet's batch norm on batch statistics), sequence_loss, clip_by_global_norm, AdamW -- one step at (2, 64, 96), iters = 2,
+    against the same procedure on the float64 oracle (`oracle.RAFT(...)(training=True)` under autograd).  Compared: the loss,
+    the UPDATE of every trainable tensor (O(lr) each: Adam's first step is lr * sign(g)-like), and that the moving statistics
+    moved toward the batch statistics."""
+    import oracle
+    import tf_raft_amd
+    from tf_raft_amd import losses, training
+    from tf_raft_amd import weights as wm
+    B, H, W, iters = 2, 64, 96, 2
+    wts = wm.condition_weights('raft', wm.init_weights('raft', seed=6, perturb=True))
+    i1 = rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32)
+    i2 = rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32)
+    flow_gt = (rng.normal(size=(B, H, W, 2)) * 2).astype(np.float32)
+    valid = rng.uniform(size=(B, H, W)) < 0.9
+    lr, wd, clip = 4e-4, 1e-4, 1.0
+    # ---- reference: oracle in float64 under autograd
+    om = oracle.RAFT(wts, iters=iters, dtype=torch.float64)
+    names = sorted(k for k in wts if 'moving' not in k)
+    for k in names:
+        om.w.t[k].requires_grad_(True)
+    preds = om([i1, i2], training=True, return_numpy=False)
+    assert len(preds) == iters
+    loss = _torch_sequence_loss(torch.tensor(flow_gt, dtype=torch.float64), torch.tensor(valid), preds, 0.8, 400)
+    loss.backward()
+    g = {k: om.w.t[k].grad for k in names}
+    gnorm = float(torch.sqrt(sum((v ** 2).sum() for v in g.values())))
+    scale = clip / max(gnorm, clip)
+    lr_t = lr * np.sqrt(1 - 0.999) / (1 - 0.9)
+    want = {}
+    for k in names:
+        gk = g[k] * scale
+        v0 = torch.tensor(wts[k], dtype=torch.float64)
+        want[k] = ((v0 - wd * v0) - lr_t * (0.1 * gk) / (torch.sqrt(0.001 * gk * gk) + 1e-7)).numpy()
+    # ---- device
+    model = tf_raft_amd.RAFT(weights=wts, iters=iters, iters_pred=3)
+    model.compile(optimizer=training.AdamW(wd, lr), clip_norm=clip, loss=losses.sequence_loss, epe=losses.end_point_error)
+    res = model.train_step((i1, i2, flow_gt, valid))
+    report('full train_step', loss=float(res['loss']), want_loss=float(loss), global_norm=gnorm)
+    np.testing.assert_allclose(float(res['loss']), float(loss), rtol=1e-4)
+    new_w = model.get_weights_dict()
+    total, bad, num, den = 0, 0, 0.0, 0.0
+    worst_group = {}
+    for k in names:
+        upd_ref = want[k] - wts[k].astype(np.float64)
+        upd_got = new_w[k].astype(np.float64) - wts[k].astype(np.float64)
+        total += upd_ref.size
+        nb = int((np.abs(upd_got - upd_ref) > 0.25 * lr).sum())
+        bad += nb
+        num += float(((upd_got - upd_ref) ** 2).sum())
+        den += float((upd_ref ** 2).sum())
+        grp = k.split('/')[0]
+        worst_group[grp] = max(worst_group.get(grp, 0.0), nb / upd_ref.size)
+    report('full train_step updated weights', frac_elements_off_by_quarter_lr=bad / total, rel_l2_of_update=float(np.sqrt(num / den)),
+           **{f'worst_tensor_frac_{k}': v for k, v in worst_group.items()})
+    # parameters whose true gradient is exactly zero (conv biases in front of a norm) get a sign from rounding noise on
+    # either side: they are the only elements allowed to differ, and they are < 0.1 % of all elements
+    assert bad / total <= 2e-3
+    assert np.sqrt(num / den) <= 0.1
+    moved = [k for k in wts if k.endswith('moving_mean') and not np.array_equal(new_w[k], wts[k])]
+    assert len(moved) == 15                                               # every batch-norm layer of cnet
+    out = model([i1, i2])
+    assert len(out) == 3 and np.isfinite(out[-1].numpy()).all()

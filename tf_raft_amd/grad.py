@@ -533,7 +533,7 @@ def encoder_forward(weights, prefix, x, training=True):
 def encoder_backward(weights, prefix, tape, d_out):
     """Backward of ``encoder_forward``: gradient w.r.t. every kernel, bias, gamma and beta of the encoder (dict under the
     weight names; the input image receives none).  Also returns the batch statistics of every batch-norm layer
-    (``{name: (mean, biased variance)}``) for the moving-average update."""
+    (``{name: (mean, biased variance, element count)}``) for the moving-average update."""
     p = prefix
     w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p + '/')}
     g, stats = {}, {}
@@ -544,7 +544,7 @@ def encoder_backward(weights, prefix, tape, d_out):
         dx, dg, db = _norm_bwd(cache, dy)
         g[f'{p}/{name}/gamma'], g[f'{p}/{name}/beta'] = dg, db
         if f'{p}/{name}/moving_mean' in w:
-            stats[f'{p}/{name}'] = (cache['mean'][0], cache['var'][0])
+            stats[f'{p}/{name}'] = (cache['mean'][0], cache['var'][0], float(cache['P']))
         return dx
 
     dy = _f32(d_out)

@@ -293,15 +293,15 @@ class RAFT:
 
 
     # ---- evaluation plumbing (reference model.py:111-170)
-    def compile(self, optimizer=None, clip_norm=None, loss=None, epe=None, trainable=None, **kwargs):
+    def compile(self, optimizer=None, clip_norm=None, loss=None, epe=None, trainable='all', **kwargs):
         """reference model.py:111-124.  ``loss`` / ``epe`` default to ``tf_raft_amd.losses.sequence_loss`` /
-        ``end_point_error``.  ``trainable``: which weights ``train_step`` updates -- only ``'update_block'`` is built so far
-        (encoders frozen; the reference trains everything), ``None`` leaves ``train_step`` unavailable."""
+        ``end_point_error``.  ``trainable``: which weights ``train_step`` updates -- ``'all'`` (the reference's behaviour:
+        encoders, norms and update block) or ``'update_block'`` (encoders frozen, run by the inference kernels)."""
         from . import losses
         if kwargs:
             raise TypeError(f'unexpected keyword arguments {sorted(kwargs)}')
-        if trainable not in (None, 'update_block'):
-            raise ValueError(f"trainable must be None or 'update_block', got {trainable!r}")
+        if trainable not in ('all', 'update_block'):
+            raise ValueError(f"trainable must be 'all' or 'update_block', got {trainable!r}")
         self.optimizer = optimizer
         self.clip_norm = clip_norm
         self.loss = loss if loss is not None else losses.sequence_loss
@@ -310,54 +310,85 @@ class RAFT:
         self._train_vars = None
         self.flow_metrics = OrderedDict((k, losses.Mean(name=k)) for k in ('loss', 'epe', 'u1', 'u3', 'u5'))
 
+    BN_MOMENTUM = 0.99      # Keras BatchNormalization default (extractor.py:10 passes none)
+
     def train_step(self, data):
-        """reference model.py:126-144 restricted to the update block (``compile(..., trainable='update_block')``): forward with
-        ``iters`` iterations (frozen encoders in inference mode, the loop in training form), ``sequence_loss``, backward
-        through time (``tf_raft_amd.grad``), ``clip_by_global_norm`` + the optimizer's ``apply_gradients`` on the device
-        (``tf_raft_amd.training.AdamW``), metrics as the reference.  Every arithmetic step is a HIP kernel; the step is
-        orchestrated from Python and re-packs the updated weights for the inference kernels afterwards -- it is the
-        functional path, not yet a tuned one.  Training the encoders (and with it the reference's full ``train_step``) is
-        not built: without ``trainable='update_block'`` this raises."""
+        """reference model.py:126-144: forward with ``iters`` iterations in training mode, ``sequence_loss``, backward,
+        ``clip_by_global_norm``, the optimizer's ``apply_gradients``, metrics.  Everything arithmetic is a HIP kernel
+        (``tf_raft_amd.grad``: encoders in training form with instance / batch-statistics norms, volume build and its
+        backward, the loop and its backward through time; ``tf_raft_amd.training.AdamW``).  With
+        ``compile(..., trainable='update_block')`` the encoders stay frozen and run on the inference kernels.
+        The step is orchestrated from Python and re-packs weights on the host for every convolution call: it is the
+        functional path (parity-tested against autograd on the oracle), not yet a tuned one.  RAFT only."""
         from . import grad, losses
         if not hasattr(self, 'flow_metrics'):
             raise RuntimeError('call compile() before train_step()')
-        if getattr(self, 'trainable', None) != 'update_block' or self.variant != 'raft':
-            raise NotImplementedError(
-                "train_step (reference model.py:126-144) is built for the update block of RAFT only: "
-                "compile(optimizer, clip_norm, loss, epe, trainable='update_block'); the backward of the encoders and of "
-                'the volume build does not exist yet')
+        if self.variant != 'raft':
+            raise NotImplementedError('train_step (reference model.py:126-144) is built for RAFT; SmallRAFT needs the backward '
+                                      'of its 3x3 ConvGRU and of upflow8')
         if self.loss is not losses.sequence_loss:
             raise NotImplementedError('train_step differentiates tf_raft_amd.losses.sequence_loss only')
         if self.optimizer is None or not hasattr(self.optimizer, 'apply_gradients'):
             raise RuntimeError('compile() needs an optimizer with apply_gradients(grads, variables, clip_norm) '
                                '(tf_raft_amd.training.AdamW)')
         image1, image2, flow, valid = data
-        image1 = _dev.to_device(image1)
-        image2 = _dev.to_device(image2)
+        image1 = _dev.to_device(image1).as_subclass(torch.Tensor).to(torch.float32)
+        image2 = _dev.to_device(image2).as_subclass(torch.Tensor).to(torch.float32)
         B, H, W, _ = image1.shape
         if H % 8 or W % 8:
             raise ValueError(f'H and W must be multiples of 8 (got {H}x{W})')
-        fmap1, fmap2 = self.fnet([image1, image2], training=False, _raw_images=True)
-        correlation = CorrBlock(fmap1, fmap2, num_levels=self.corr_levels, radius=self.corr_radius)
-        cnet = self.cnet(image1, training=False, _raw_images=True)
         h, w = H // 8, W // 8
+        full = self.trainable == 'all'
+        wts = self._weights
+        if full:
+            ones = torch.ones_like(image1)
+            x1 = grad._axpby(2.0 / 255.0, image1.contiguous(), -1.0, ones)            # model.py:70-71
+            x2 = grad._axpby(2.0 / 255.0, image2.contiguous(), -1.0, ones)
+            fout, ftape = grad.encoder_forward(wts, 'fnet', torch.cat([x1, x2], dim=0), training=True)     # model.py:74
+            fout = fout.as_subclass(torch.Tensor)
+            fmap1, fmap2 = fout[:B].contiguous(), fout[B:].contiguous()
+            cnet, ctape = grad.encoder_forward(wts, 'cnet', x1, training=True)         # model.py:82
+        else:
+            fmap1, fmap2 = self.fnet([image1, image2], training=False, _raw_images=True)
+            cnet = self.cnet(image1, training=False, _raw_images=True)
+        correlation = CorrBlock(fmap1, fmap2, num_levels=self.corr_levels, radius=self.corr_radius)   # model.py:77
         st = self._get_state(B, h, w, image1.device)
         check(_dev.lib().raft_prepare_state_f32(_dev.ptr(cnet), st.B, st.h, st.w, C.byref(st.c), _dev.stream_ptr()),
-              'prepare_state')                                             # model.py:84-86: net = tanh(.), inp = relu(.)
+              'prepare_state')                                                        # model.py:84-86
         net0 = st.net.clone()
         inp = st.x[..., :self.context_dim].contiguous()
         prefix = 'update_block'
-        ub = {k: v for k, v in self._weights.items() if k.startswith(prefix)}
+        ub = {k: v for k, v in wts.items() if k.startswith(prefix)}
         preds, tape = grad.loop_forward(ub, correlation, net0, inp, self.iters, prefix)
         loss = self.loss([flow, valid], preds)
         d_preds = grad.sequence_loss_grad((flow, valid), preds)
-        _, _, _, wg = grad.loop_backward(ub, correlation, tape, d_preds, prefix)
-        if self._train_vars is None:
-            self._train_vars = {k: _dev.to_device(np.ascontiguousarray(v)).as_subclass(torch.Tensor).clone() for k, v in ub.items()}
-        self.optimizer.apply_gradients({k: wg[k] for k in self._train_vars}, self._train_vars, clip_norm=self.clip_norm)
+        d_net0, d_inp, d_pyr, grads = grad.loop_backward(ub, correlation, tape, d_preds, prefix)
+        stats = {}
+        if full:
+            d_f1, d_f2 = grad.corr_build_backward(correlation, d_pyr)
+            d_fout = torch.cat([d_f1.as_subclass(torch.Tensor), d_f2.as_subclass(torch.Tensor)], dim=0).contiguous()
+            gf, _ = grad.encoder_backward(wts, 'fnet', ftape, d_fout)
+            d_cnet = grad.prepare_state_backward(net0, inp, d_net0, d_inp)
+            gc, stats = grad.encoder_backward(wts, 'cnet', ctape, d_cnet)
+            grads = dict(grads)
+            grads.update(gf)
+            grads.update(gc)
+        names = sorted(grads)
+        if self._train_vars is None or sorted(self._train_vars) != names:
+            self._train_vars = {k: _dev.to_device(np.ascontiguousarray(wts[k])).as_subclass(torch.Tensor).clone() for k in names}
+        self.optimizer.apply_gradients({k: grads[k].as_subclass(torch.Tensor).reshape(self._train_vars[k].shape) for k in names},
+                                       self._train_vars, clip_norm=self.clip_norm)
         for k, v in self._train_vars.items():
-            self._weights[k] = v.detach().cpu().numpy()
-        self.update_block.set_weights(self._weights)
+            wts[k] = v.detach().cpu().numpy()
+        # Keras BatchNormalization moving statistics (momentum 0.99).  TF 2.3's fused kernel feeds the moving variance with
+        # the UNBIASED batch variance; that detail cannot be checked here (no TensorFlow) and is stated in DESIGN.md.
+        for name, (mean, var, cnt) in stats.items():
+            mm = _dev.to_device(np.ascontiguousarray(wts[f'{name}/moving_mean'])).as_subclass(torch.Tensor)
+            mv = _dev.to_device(np.ascontiguousarray(wts[f'{name}/moving_variance'])).as_subclass(torch.Tensor)
+            wts[f'{name}/moving_mean'] = grad._axpby(self.BN_MOMENTUM, mm, 1.0 - self.BN_MOMENTUM, mean.contiguous()).cpu().numpy()
+            wts[f'{name}/moving_variance'] = grad._axpby(self.BN_MOMENTUM, mv, (1.0 - self.BN_MOMENTUM) * cnt / max(cnt - 1.0, 1.0),
+                                                         var.contiguous()).cpu().numpy()
+        self.set_weights(wts)                       # hands the new weights to the inference kernels (re-packs on the host)
         info = self.epe([flow, valid], preds[-1])
         self.flow_metrics['loss'].update_state(loss)
         for k in ('epe', 'u1', 'u3', 'u5'):
