@@ -175,6 +175,7 @@ def test_end_point_error_metric_and_test_step(rng):
     assert out['loss'] == 0.0                      # only train_step feeds it
     model.reset_metrics()
     assert all(m.count == 0 for m in model.flow_metrics.values())
+    import tf_raft_amd
     small = tf_raft_amd.SmallRAFT(iters_pred=2)
     small.compile()
     with pytest.raises(NotImplementedError):       # train_step is built for RAFT only

@@ -3,9 +3,9 @@ pass with ``tf.GradientTape``; BASELINE config 5).  What exists: the gradient of
 prediction, the backward of the pyramid lookup (``CorrBlock.retrieve`` + ``bilinear_sampler``) w.r.t. the coordinates and
 the correlation pyramid, and the backward of one Keras ``Conv2D`` (+ relu) w.r.t. input, kernel and bias -- each a HIP
 kernel behind the C ABI (``csrc/backward.hip``), deterministic, checked against torch autograd of the CPU oracle in
-``tests/test_gpu_backward.py``.  The remaining pieces of ``train_step`` (backward of the GRU gates, the convex upsampling,
-the encoders and norms; global-norm clipping, AdamW, the RCCL gradient all-reduce) are not built yet:
-``RAFT.train_step`` still raises.
+``tests/test_gpu_backward.py``.  The later sections of this module add the rest of ``train_step``: one whole update block,
+the loop and its backward through time, the volume build, the encoders with their norms.  torch allocates, slices and
+concatenates here; every multiply-add is a HIP kernel.
 """
 from __future__ import annotations
 

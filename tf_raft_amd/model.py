@@ -17,9 +17,9 @@ the current HIP stream with no host synchronisation.  There is no CPU fallback.
 Callers of the forward pass (reference model.py:111-170): ``compile``, ``test_step`` (EPE / u1 / u3 / u5 of the final
 prediction against ground truth, reduced on the device: ``tf_raft_amd.losses``), ``predict_step``, ``reset_metrics``,
 ``load_weights`` / ``save_weights`` (TensorFlow tensor-bundle checkpoints, read and written without TensorFlow) are
-provided.  ``train_step`` exists for the update block (``compile(..., trainable='update_block')``: backward through time on
-HIP kernels, global-norm clipping, AdamW -- ``tf_raft_amd.grad`` / ``tf_raft_amd.training``); training the encoders is not
-built and the reference's full ``train_step`` therefore still raises ``NotImplementedError``.
+provided.  ``train_step`` (model.py:126-144) is functional for RAFT: training-mode forward, backward, global-norm clipping
+and AdamW on HIP kernels (``tf_raft_amd.grad`` / ``tf_raft_amd.training``), orchestrated from Python -- not yet a tuned
+path.
 """
 from __future__ import annotations
 
