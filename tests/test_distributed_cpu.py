@@ -98,3 +98,49 @@ def test_empty_global_batch_is_rejected():
     from tf_raft_amd.parallel import predict_sharded
     with pytest.raises(ValueError):
         predict_sharded(lambda xs: [xs[0]], torch.zeros((0, 8, 8, 3)), torch.zeros((0, 8, 8, 3)))
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tf_raft_amd.parallel import all_reduce_gradients
+    rng = np.random.default_rng(100 + rank)
+    grads = {f'layer{i}/kernel': torch.as_tensor(rng.normal(size=(3, 3, 4, 5 + i)).astype(np.float32)) for i in range(6)}
+    grads['layer0/bias'] = torch.as_tensor(rng.normal(size=(5,)).astype(np.float32))
+    all_reduce_gradients(grads, bucket_bytes=1024)           # small buckets: several collectives, ragged last one
+    np.savez(os.path.join(out_dir, f'g{rank}.npz'), **{k.replace('/', '|'): v.numpy() for k, v in grads.items()})
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_averages_over_ranks(tmp_path):
+    """The N > 1 path of train_step (BASELINE config 5): bucketed all-reduce of the gradient dict, world size 2, gloo."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [np.load(tmp_path / f'g{r}.npz') for r in range(2)]
+    for key in got[0].files:
+        name = key.replace('|', '/')
+        parts = []
+        for r in range(2):
+            rng = np.random.default_rng(100 + r)
+            ref = {f'layer{i}/kernel': rng.normal(size=(3, 3, 4, 5 + i)).astype(np.float32) for i in range(6)}
+            ref['layer0/bias'] = rng.normal(size=(5,)).astype(np.float32)
+            parts.append(ref[name])
+        want = (parts[0] + parts[1]) / 2
+        np.testing.assert_allclose(got[0][key], want, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(got[0][key], got[1][key])          # every rank holds the same average
+
+
+def test_learning_rate_schedule_and_scalers():
+    """reference training.py:10-23 + tfa CyclicalLearningRate (train_sintel.py:83-89): triangular first cycle, then flat."""
+    from tf_raft_amd import training
+    assert training.first_cycle_scaler(1) == 1.0 and training.first_cycle_scaler(2) == 0.0
+    assert training.inverse_scaler(4) == 0.25
+    sched = training.CyclicalLearningRate(1e-4, 2e-4, step_size=1000, scale_fn=training.first_cycle_scaler, scale_mode='cycle')
+    assert sched(0) == pytest.approx(1e-4) and sched(500) == pytest.approx(1.5e-4) and sched(1000) == pytest.approx(2e-4)
+    assert sched(1500) == pytest.approx(1.5e-4) and sched(2000) == pytest.approx(1e-4) and sched(2600) == pytest.approx(1e-4)
+    inv = training.CyclicalLearningRate(1e-4, 2e-4, step_size=10, scale_fn=training.inverse_scaler)
+    assert inv(30) == pytest.approx(1e-4 + 1e-4 * 0.5)                   # peak of the second cycle, scaled by 1/2
+    with pytest.raises(ValueError):
+        training.CyclicalLearningRate(1e-4, 2e-4, 10, scale_mode='epoch')

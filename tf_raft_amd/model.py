@@ -376,8 +376,10 @@ class RAFT:
         names = sorted(grads)
         if self._train_vars is None or sorted(self._train_vars) != names:
             self._train_vars = {k: _dev.to_device(np.ascontiguousarray(wts[k])).as_subclass(torch.Tensor).clone() for k in names}
-        self.optimizer.apply_gradients({k: grads[k].as_subclass(torch.Tensor).reshape(self._train_vars[k].shape) for k in names},
-                                       self._train_vars, clip_norm=self.clip_norm)
+        gt = {k: grads[k].as_subclass(torch.Tensor).reshape(self._train_vars[k].shape).contiguous() for k in names}
+        from .parallel import all_reduce_gradients
+        all_reduce_gradients(gt)                    # data-parallel training: one bucketed RCCL all-reduce (no-op on one rank)
+        self.optimizer.apply_gradients(gt, self._train_vars, clip_norm=self.clip_norm)
         for k, v in self._train_vars.items():
             wts[k] = v.detach().cpu().numpy()
         # Keras BatchNormalization moving statistics (momentum 0.99).  TF 2.3's fused kernel feeds the moving variance with
