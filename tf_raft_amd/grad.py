@@ -22,6 +22,27 @@ def _f32(t):
     return _dev.to_device(t).as_subclass(torch.Tensor).to(torch.float32).contiguous()
 
 
+# Packed-weight cache of one training step: the functional path packs Keras-layout kernels on the host for the generic
+# convolution kernels; within a step the same kernel is used by every loop iteration (forward, and flipped for the input
+# gradient).  Keyed by the identity of the source array, which is kept alive by the entry; ``clear_pack_cache()`` is called by
+# ``RAFT.train_step`` at the start of every step (the optimizer replaces the arrays).
+_PACK = {}
+
+
+def clear_pack_cache():
+    _PACK.clear()
+
+
+def _cached(arr, tag, make, also=None):
+    """``make()`` memoised on the identity of ``arr`` (and of ``also``); both are kept alive by the entry."""
+    key = (id(arr), id(also), tag)
+    hit = _PACK.get(key)
+    if hit is None or hit[0] is not arr or hit[1] is not also:
+        hit = (arr, also, make())
+        _PACK[key] = hit
+    return hit[2]
+
+
 def sequence_loss_grad(y_true, y_pred, gamma=0.8, max_flow=400, upstream=1.0):
     """d ``sequence_loss(y_true, y_pred)`` / d ``y_pred[i]`` for every i (reference losses.py:4-21): list of tensors shaped
     like the predictions."""
@@ -93,12 +114,15 @@ def conv2d_backward(x, kernel, dy, y=None):
                                     _dev.ptr(d_bias), _dev.ptr(ws), _dev.stream_ptr()), 'conv2d_wgrad')
     # input gradient: the forward convolution of dy with the flipped, transposed kernel
     cpad = packing.round_up(cout, 32)
-    wp, b, npad = packing.pack_conv_dgrad(kernel, [(cout, cpad)])
+
+    def make():
+        wp, b, npad_ = packing.pack_conv_dgrad(kernel, [(cout, cpad)])
+        return _dev.to_device(wp), _dev.to_device(b), npad_
+    wp_d, b_d, npad = _cached(kernel, 'dgrad', make)
     dyp = dy
     if cpad != cout:
         dyp = torch.zeros((B, H, W, cpad), device=x.device, dtype=torch.float32)
         dyp[..., :cout] = dy
-    wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
     dx = torch.empty((B, H, W, cin), device=x.device, dtype=torch.float32)
     check(lib.raft_conv2d_f32(_dev.ptr(dyp), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw, npad,
                               cin, 0, 1.0, _dev.ptr(dx), cin, _dev.stream_ptr()), 'conv2d dgrad')
@@ -115,12 +139,15 @@ def _conv_fwd(x, kernel, bias, act=0, scale=1.0):
     kh, kw, cin, cout = kernel.shape
     B, H, W, c = x.shape
     cpad = packing.round_up(cin, 32)
-    wp, b, npad = packing.pack_conv(kernel, bias, [(cin, cpad)])
+
+    def make():
+        wp, b, npad_ = packing.pack_conv(kernel, bias, [(cin, cpad)])
+        return _dev.to_device(wp), _dev.to_device(b), npad_
+    wp_d, b_d, npad = _cached(kernel, 'fwd', make, also=bias) if isinstance(bias, np.ndarray) else make()
     xp = x
     if cpad != c:
         xp = torch.zeros((B, H, W, cpad), device=x.device, dtype=torch.float32)
         xp[..., :c] = x
-    wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
     out = torch.empty((B, H, W, cout), device=x.device, dtype=torch.float32)
     check(_dev.lib().raft_conv2d_f32(_dev.ptr(xp), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw, npad,
                                      cout, act, float(scale), _dev.ptr(out), cout, _dev.stream_ptr()), 'conv2d')
@@ -140,8 +167,11 @@ def _conv_bwd(x, kernel, dy, y=None):
     kh, kw, cin, cout = kernel.shape
     ci4, co4 = packing.round_up(cin, 4), packing.round_up(cout, 4)
     if ci4 != cin or co4 != cout:
-        kp = np.zeros((kh, kw, ci4, co4), np.float32)
-        kp[:, :, :cin, :cout] = kernel
+        def pad():
+            kp_ = np.zeros((kh, kw, ci4, co4), np.float32)
+            kp_[:, :, :cin, :cout] = kernel
+            return kp_
+        kp = _cached(kernel, 'pad4', pad)
         B, H, W, _ = x.shape
         xp = torch.zeros((B, H, W, ci4), device=x.device, dtype=torch.float32)
         xp[..., :cin] = x
@@ -173,8 +203,8 @@ def basic_update_block_forward(weights, net, inp, corr, flow, prefix='update_blo
     conv = lambda name, x, act=0, scale=1.0: _conv_fwd(x, w[f'{p}/{name}/kernel'], w[f'{p}/{name}/bias'], act, scale)
     s['cor1'] = conv('encoder/convc1', corr, 1)
     s['cor2'] = conv('encoder/convc2', s['cor1'], 1)
-    k7 = _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, 128))
-    b7 = _dev.to_device(w[f'{p}/encoder/convf1/bias'])
+    k7 = _cached(w[f'{p}/encoder/convf1/kernel'], 'k7', lambda: _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, 128)))
+    b7 = _cached(w[f'{p}/encoder/convf1/bias'], 'b7', lambda: _dev.to_device(w[f'{p}/encoder/convf1/bias']))
     s['flo1'] = torch.empty((B, H, W, 128), device=net.device, dtype=torch.float32)
     check(lib.raft_conv7x7_c2_f32(_dev.ptr(flow), _dev.ptr(k7), _dev.ptr(b7), 128, B, H, W, _dev.ptr(s['flo1']), 128,
                                   _dev.stream_ptr()), 'conv7x7_c2')
@@ -185,8 +215,10 @@ def basic_update_block_forward(weights, net, inp, corr, flow, prefix='update_blo
     s['x'] = x
     h = net
     for g in ('1', '2'):                                                           # update.py:51-67
-        kzr = np.concatenate([w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3)
-        bzr = np.concatenate([w[f'{p}/gru/convz{g}/bias'], w[f'{p}/gru/convr{g}/bias']])
+        kzr = _cached(w[f'{p}/gru/convz{g}/kernel'], 'kzr', lambda: np.concatenate(
+            [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3))
+        bzr = _cached(w[f'{p}/gru/convz{g}/bias'], 'bzr', lambda: np.concatenate(
+            [w[f'{p}/gru/convz{g}/bias'], w[f'{p}/gru/convr{g}/bias']]))
         hx = torch.cat([h, x], dim=-1).contiguous()
         a_zr = _conv_fwd(hx, kzr, bzr)
         z, r, rh = (torch.empty_like(h) for _ in range(3))
@@ -249,7 +281,8 @@ def basic_update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='
         dr_pre = torch.empty_like(h_in)
         check(lib.raft_gru_gate_r_backward_f32(_dev.ptr(d_rh), _dev.ptr(r), _dev.ptr(h_in), n_h, _dev.ptr(dr_pre), _dev.ptr(dh_in),
                                                _dev.stream_ptr()), 'gate_r_backward')
-        kzr = np.concatenate([w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3)
+        kzr = _cached(w[f'{p}/gru/convz{g}/kernel'], 'kzr', lambda: np.concatenate(
+            [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3))
         d_zr = torch.cat([dz_pre, dr_pre], dim=-1).contiguous()
         d_hx, dk, db = conv_b(None, s[f'hx{g}'], d_zr, kernel=kzr)
         grads[f'{p}/gru/convz{g}/kernel'], grads[f'{p}/gru/convr{g}/kernel'] = dk[..., :128].contiguous(), dk[..., 128:].contiguous()
@@ -270,7 +303,7 @@ def basic_update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='
     masked = torch.empty_like(d_flo1)
     check(lib.raft_relu_backward_f32(_dev.ptr(s['flo1']), _dev.ptr(d_flo1), _dev.ptr(masked), masked.numel(), _dev.stream_ptr()),
           'relu_backward')
-    k7 = _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, 128))
+    k7 = _cached(w[f'{p}/encoder/convf1/kernel'], 'k7', lambda: _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, 128)))
     d_flow_f = torch.empty((B, H, W, 2), device=d_net.device, dtype=torch.float32)
     dk7 = torch.empty((98, 128), device=d_net.device, dtype=torch.float32)
     db7 = torch.empty((128,), device=d_net.device, dtype=torch.float32)

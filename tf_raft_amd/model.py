@@ -340,6 +340,7 @@ class RAFT:
         h, w = H // 8, W // 8
         full = self.trainable == 'all'
         wts = self._weights
+        grad.clear_pack_cache()                     # packed copies of last step's weights
         if full:
             ones = torch.ones_like(image1)
             x1 = grad._axpby(2.0 / 255.0, image1.contiguous(), -1.0, ones)            # model.py:70-71
