@@ -86,6 +86,7 @@ class RAFT:
     def set_weights(self, weights: Dict[str, np.ndarray]) -> None:
         weights_mod.check_weights(self.variant, weights)
         self._weights = dict(weights)
+        self._inference_stale = False
         self._train_vars = None                     # train_step re-reads its device master copies
         self.fnet.set_weights(weights)
         self.cnet.set_weights(weights)
@@ -233,7 +234,15 @@ class RAFT:
         """reference model.py:68-109."""
         return self._forward(inputs, training)
 
+    def _sync_inference_weights(self):
+        if getattr(self, '_inference_stale', False):
+            keep = self._train_vars
+            self.set_weights(self._weights)
+            self._train_vars = keep
+            self._inference_stale = False
+
     def _forward(self, inputs, training=False, final_only=False):
+        self._sync_inference_weights()
         image1, image2 = inputs
         image1 = _dev.to_device(image1)
         image2 = _dev.to_device(image2)
@@ -391,7 +400,9 @@ class RAFT:
             wts[f'{name}/moving_mean'] = grad._axpby(self.BN_MOMENTUM, mm, 1.0 - self.BN_MOMENTUM, mean.contiguous()).cpu().numpy()
             wts[f'{name}/moving_variance'] = grad._axpby(self.BN_MOMENTUM, mv, (1.0 - self.BN_MOMENTUM) * cnt / max(cnt - 1.0, 1.0),
                                                          var.contiguous()).cpu().numpy()
-        self.set_weights(wts)                       # hands the new weights to the inference kernels (re-packs on the host)
+        # the inference kernels take re-packed (Winograd-transformed, N-fused) copies: made lazily by the next forward call
+        self._weights = dict(wts)
+        self._inference_stale = True
         info = self.epe([flow, valid], preds[-1])
         self.flow_metrics['loss'].update_state(loss)
         for k in ('epe', 'u1', 'u3', 'u5'):
