@@ -303,7 +303,7 @@ def test_tuning_switches_are_a_table_not_getenv():
 
 
 @pytest.mark.parametrize('path', ['tf_raft.model', 'tf_raft.losses', 'tf_raft.losses.losses', 'tf_raft.layers.corr',
-                                  'tf_raft.layers.update', 'tf_raft.layers.extractor'])
+                                  'tf_raft.layers.update', 'tf_raft.layers.extractor', 'tf_raft.training'])
 def test_every_reference_import_path_resolves(path):
     """The reference's own import statements (train_sintel.py:8-9, tf_raft/model.py:4-6, tests/) work on the shim."""
     import importlib
@@ -313,7 +313,8 @@ def test_every_reference_import_path_resolves(path):
              'tf_raft.losses.losses': ['sequence_loss', 'end_point_error', 'EndPointError'],
              'tf_raft.layers.corr': ['CorrBlock', 'bilinear_sampler', 'coords_grid', 'upflow8'],
              'tf_raft.layers.update': ['BasicUpdateBlock', 'SmallUpdateBlock'],
-             'tf_raft.layers.extractor': ['BasicEncoder', 'SmallEncoder']}[path]
+             'tf_raft.layers.extractor': ['BasicEncoder', 'SmallEncoder'],
+             'tf_raft.training': ['first_cycle_scaler', 'inverse_scaler']}[path]
     for n in names:
         assert hasattr(mod, n), (path, n)
 
