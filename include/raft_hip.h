@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 207          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 208          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -522,6 +522,9 @@ int raft_norm_backward_f32(const float *x, const float *dy, const float *mean, c
                            int64_t P, int C, float *dx, float *dgamma, float *dbeta, double *workspace, void *stream);
 /* out = relu(alpha * a + beta * b): the residual join of a ResBlock (extractor.py:49). */
 int raft_axpby_relu_f32(float alpha, const float *a, float beta, const float *b, float *out, int64_t n, void *stream);
+
+/* Backward of raft_upflow8_f32 (corr.py:93-96): d_up (B, 8h, 8w, 2) -> d_flow (B, h, w, 2), a deterministic gather. */
+int raft_upflow8_backward_f32(const float *d_up, int B, int h, int w, float *d_flow, void *stream);
 
 #ifdef __cplusplus
 }

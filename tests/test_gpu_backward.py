@@ -558,3 +558,98 @@ def test_full_train_step_matches_reference_semantics(rng):
     assert len(moved) == 15                                               # every batch-norm layer of cnet
     out = model([i1, i2])
     assert len(out) == 3 and np.isfinite(out[-1].numpy()).all()
+
+
+def test_small_update_block_backward_matches_autograd(rng):
+    """SmallUpdateBlock (reference update.py:109-125: SmallMotionEncoder, 3x3 ConvGRU, FlowHead(128), no mask) in training
+    form and its backward against autograd."""
+    from oracle.layers import W, small_update_block
+    from tf_raft_amd import grad
+    from tf_raft_amd import weights as wm
+    B, h, w = 2, 9, 13
+    wts = {k: v for k, v in wm.init_weights('small', seed=8, perturb=True).items() if k.startswith('update_block')}
+    net = np.tanh(rng.normal(size=(B, h, w, 96))).astype(np.float32)
+    inp = np.maximum(rng.normal(size=(B, h, w, 64)), 0).astype(np.float32)
+    corr = rng.normal(size=(B, h, w, 196)).astype(np.float32)
+    flow = (rng.normal(size=(B, h, w, 2)) * 2).astype(np.float32)
+    ow = W(wts, torch.float64)
+    for t in ow.t.values():
+        t.requires_grad_(True)
+    tin = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (net, inp, corr, flow)]
+    rn, rm, rd = small_update_block(ow, 'update_block', *tin)
+    gn, gm, gd, saved = grad.update_block_forward(wts, net, inp, corr, flow, variant='small')
+    assert rm is None and gm is None
+    assert float(np.abs(_np(gn) - rn.detach().numpy()).max()) <= 5e-5 and float(np.abs(_np(gd) - rd.detach().numpy()).max()) <= 5e-5
+    d_net, d_delta = rng.normal(size=rn.shape).astype(np.float32), rng.normal(size=rd.shape).astype(np.float32)
+    torch.autograd.backward([rn, rd], [torch.tensor(a, dtype=torch.float64) for a in (d_net, d_delta)])
+    din, dw = grad.update_block_backward(wts, saved, d_net, None, d_delta)
+    worst = 0.0
+    for name, t in zip(('net', 'inp', 'corr', 'flow'), tin):
+        want = t.grad.numpy()
+        worst = max(worst, float(np.abs(_np(din[name]) - want).max() / max(1.0, np.abs(want).max())))
+    assert len(dw) == 18
+    for name, got in dw.items():
+        want = ow.t[name].grad.numpy()
+        assert _np(got).shape == want.shape, name
+        worst = max(worst, float(np.abs(_np(got) - want).max() / max(1.0, np.abs(want).max())))
+    report('small update block backward', worst_rel_err_over_22_gradients=worst)
+    assert worst <= 5e-5
+
+
+def test_upflow8_backward_matches_autograd(rng):
+    from oracle.corr import upflow8
+    from tf_raft_amd import grad
+    for B, h, w in ((2, 5, 7), (1, 1, 3)):
+        flow = torch.tensor(rng.normal(size=(B, h, w, 2)), dtype=torch.float64, requires_grad=True)
+        d_up = rng.normal(size=(B, 8 * h, 8 * w, 2)).astype(np.float32)
+        upflow8(flow).backward(torch.tensor(d_up, dtype=torch.float64))
+        got = _np(grad.upflow8_backward(d_up, B, h, w))
+        rel = float(np.abs(got - flow.grad.numpy()).max() / np.abs(flow.grad.numpy()).max())
+        report(f'upflow8 backward {(B, h, w)}', rel_err=rel)
+        assert rel <= 1e-5
+
+
+def test_small_raft_train_step_matches_reference_semantics(rng):
+    """SmallRAFT.train_step (reference model.py:173-226 forward, 126-144 step): one step at (2, 64, 96), iters = 2, all weights
+    trainable, against the float64 oracle under autograd."""
+    import oracle
+    import tf_raft_amd
+    from tf_raft_amd import losses, training
+    from tf_raft_amd import weights as wm
+    B, H, W, iters = 2, 64, 96, 2
+    wts = wm.condition_weights('small', wm.init_weights('small', seed=4, perturb=True))
+    i1 = rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32)
+    i2 = rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32)
+    flow_gt = (rng.normal(size=(B, H, W, 2)) * 2).astype(np.float32)
+    valid = rng.uniform(size=(B, H, W)) < 0.9
+    lr, wd, clip = 4e-4, 1e-4, 1.0
+    om = oracle.SmallRAFT(wts, iters=iters, dtype=torch.float64)
+    names = sorted(wts)
+    for k in names:
+        om.w.t[k].requires_grad_(True)
+    preds = om([i1, i2], training=True, return_numpy=False)
+    loss = _torch_sequence_loss(torch.tensor(flow_gt, dtype=torch.float64), torch.tensor(valid), preds, 0.8, 400)
+    loss.backward()
+    g = {k: om.w.t[k].grad for k in names}
+    gnorm = float(torch.sqrt(sum((v ** 2).sum() for v in g.values())))
+    scale = clip / max(gnorm, clip)
+    lr_t = lr * np.sqrt(1 - 0.999) / (1 - 0.9)
+    model = tf_raft_amd.SmallRAFT(weights=wts, iters=iters, iters_pred=3)
+    model.compile(optimizer=training.AdamW(wd, lr), clip_norm=clip, loss=losses.sequence_loss, epe=losses.end_point_error)
+    res = model.train_step((i1, i2, flow_gt, valid))
+    np.testing.assert_allclose(float(res['loss']), float(loss), rtol=1e-4)
+    new_w = model.get_weights_dict()
+    total, bad, num, den = 0, 0, 0.0, 0.0
+    for k in names:
+        gk = g[k] * scale
+        v0 = torch.tensor(wts[k], dtype=torch.float64)
+        want = ((v0 - wd * v0) - lr_t * (0.1 * gk) / (torch.sqrt(0.001 * gk * gk) + 1e-7)).numpy()
+        upd_ref, upd_got = want - wts[k], new_w[k].astype(np.float64) - wts[k]
+        total += upd_ref.size
+        bad += int((np.abs(upd_got - upd_ref) > 0.25 * lr).sum())
+        num += float(((upd_got - upd_ref) ** 2).sum())
+        den += float((upd_ref ** 2).sum())
+    report('SmallRAFT train_step', loss=float(res['loss']), frac_elements_off_by_quarter_lr=bad / total,
+           rel_l2_of_update=float(np.sqrt(num / den)))
+    assert bad / total <= 2e-3 and np.sqrt(num / den) <= 0.1
+    assert np.isfinite(model([i1, i2])[-1].numpy()).all()

@@ -1099,3 +1099,52 @@ extern "C" int raft_axpby_relu_f32(float alpha, const float *a, float beta, cons
     axpby_relu_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(alpha, a, beta, b, out, n);
     return raft_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// upflow8 backward (reference corr.py:93-96: 8 * tf.image.resize(flow, 8x, 'bilinear'), half-pixel centres): the adjoint as a
+// deterministic GATHER -- low-resolution pixel (y, x) collects, from every output pixel within reach, the weight that
+// pixel's interpolation puts on it (src = (dst + 0.5) / 8 - 0.5, lo = max(floor(src), 0), hi = min(ceil(src), n - 1),
+// lerp = src - floor(src); both taps of a clamped output land on the same index and simply add).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void resize_tap(int dst, int n, int *lo, int *hi, float *lerp) {
+    const float src = ((float)dst + 0.5f) * 0.125f - 0.5f;
+    const float fl = floorf(src);
+    *lo = max((int)fl, 0);
+    *hi = min((int)ceilf(src), n - 1);
+    *lerp = src - fl;
+}
+__global__ void __launch_bounds__(256) upflow8_bwd_kernel(const float *__restrict__ d_up, int B, int h, int w, float *__restrict__ d_flow) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * h * w) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h);
+    const int64_t b = i / ((int64_t)w * h);
+    const int H8 = 8 * h, W8 = 8 * w;
+    float ax = 0.f, ay = 0.f;
+    for (int Y = max(0, 8 * y - 8); Y <= min(H8 - 1, 8 * y + 15); ++Y) {
+        int ylo, yhi;
+        float yl;
+        resize_tap(Y, h, &ylo, &yhi, &yl);
+        const float wy = (ylo == y ? 1.0f - yl : 0.f) + (yhi == y ? yl : 0.f);
+        if (wy == 0.f) continue;
+        for (int X = max(0, 8 * x - 8); X <= min(W8 - 1, 8 * x + 15); ++X) {
+            int xlo, xhi;
+            float xl;
+            resize_tap(X, w, &xlo, &xhi, &xl);
+            const float wx = (xlo == x ? 1.0f - xl : 0.f) + (xhi == x ? xl : 0.f);
+            if (wx == 0.f) continue;
+            const float2 g = *(const float2 *)(d_up + ((b * H8 + Y) * (int64_t)W8 + X) * 2);
+            ax = fmaf(wy * wx, g.x, ax);
+            ay = fmaf(wy * wx, g.y, ay);
+        }
+    }
+    *(float2 *)(d_flow + i * 2) = make_float2(8.0f * ax, 8.0f * ay);
+}
+}   // namespace
+
+extern "C" int raft_upflow8_backward_f32(const float *d_up, int B, int h, int w, float *d_flow, void *stream) {
+    RAFT_REQUIRE_PTR(d_up); RAFT_REQUIRE_PTR(d_flow);
+    RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
+    upflow8_bwd_kernel<<<raft_ceil_div((int64_t)B * h * w, 256), 256, 0, (hipStream_t)stream>>>(d_up, B, h, w, d_flow);
+    return raft_launch_status();
+}

@@ -188,33 +188,43 @@ def _conv_bwd(x, kernel, dy, y=None):
     return dx.as_subclass(torch.Tensor), dk.as_subclass(torch.Tensor), db.as_subclass(torch.Tensor)
 
 
-def basic_update_block_forward(weights, net, inp, corr, flow, prefix='update_block'):
-    """``BasicUpdateBlock([net, inp, corr, flow])`` (reference update.py:143-153) in TRAINING form: every layer a generic
-    HIP convolution with a linear / relu epilogue, the GRU gates as separate kernels, every activation the backward needs
-    kept.  Returns ``(net, mask, delta_flow, saved)``.  (The inference path fuses gates and branches into its kernels and
-    keeps nothing; both compute the same function: ``tests/test_gpu_backward.py`` checks this one against the oracle.)"""
+_UB = {
+    # reference update.py:128-153 (BasicUpdateBlock) / 109-125 (SmallUpdateBlock)
+    'raft': dict(hdim=128, cdim=128, convc2=True, cor=192, flo=64, cf1=128, mot=126, gru=('1', '2'), mask=True),
+    'small': dict(hdim=96, cdim=64, convc2=False, cor=96, flo=32, cf1=64, mot=80, gru=('',), mask=False),
+}
+
+
+def update_block_forward(weights, net, inp, corr, flow, prefix='update_block', variant='raft'):
+    """``BasicUpdateBlock`` / ``SmallUpdateBlock`` ``([net, inp, corr, flow])`` (reference update.py:143-153 / 118-125) in
+    TRAINING form: every layer a generic HIP convolution with a linear / relu epilogue, the GRU gates as separate kernels,
+    every activation the backward needs kept.  Returns ``(net, mask, delta_flow, saved)`` (``mask`` is None for the small
+    block).  (The inference path fuses gates and branches into its kernels and keeps nothing; both compute the same
+    function: ``tests/test_gpu_backward.py`` checks this one against the oracle.)"""
     lib = _dev.lib()
-    p = prefix
+    p, cfg = prefix, _UB[variant]
+    hd = cfg['hdim']
     w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p)}
     net, inp, corr, flow = (_f32(t) for t in (net, inp, corr, flow))
     B, H, W, _ = net.shape
     M = B * H * W
-    s = {'net0': net, 'inp': inp, 'corr': corr, 'flow': flow}
+    s = {'net0': net, 'inp': inp, 'corr': corr, 'flow': flow, 'variant': variant}
     conv = lambda name, x, act=0, scale=1.0: _conv_fwd(x, w[f'{p}/{name}/kernel'], w[f'{p}/{name}/bias'], act, scale)
     s['cor1'] = conv('encoder/convc1', corr, 1)
-    s['cor2'] = conv('encoder/convc2', s['cor1'], 1)
-    k7 = _cached(w[f'{p}/encoder/convf1/kernel'], 'k7', lambda: _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, 128)))
+    s['cor2'] = conv('encoder/convc2', s['cor1'], 1) if cfg['convc2'] else s['cor1']
+    cf1 = cfg['cf1']
+    k7 = _cached(w[f'{p}/encoder/convf1/kernel'], 'k7', lambda: _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, cf1)))
     b7 = _cached(w[f'{p}/encoder/convf1/bias'], 'b7', lambda: _dev.to_device(w[f'{p}/encoder/convf1/bias']))
-    s['flo1'] = torch.empty((B, H, W, 128), device=net.device, dtype=torch.float32)
-    check(lib.raft_conv7x7_c2_f32(_dev.ptr(flow), _dev.ptr(k7), _dev.ptr(b7), 128, B, H, W, _dev.ptr(s['flo1']), 128,
+    s['flo1'] = torch.empty((B, H, W, cf1), device=net.device, dtype=torch.float32)
+    check(lib.raft_conv7x7_c2_f32(_dev.ptr(flow), _dev.ptr(k7), _dev.ptr(b7), cf1, B, H, W, _dev.ptr(s['flo1']), cf1,
                                   _dev.stream_ptr()), 'conv7x7_c2')
     s['flo2'] = conv('encoder/convf2', s['flo1'], 1)
-    s['corflo'] = torch.cat([s['cor2'], s['flo2']], dim=-1)                       # update.py:104
+    s['corflo'] = torch.cat([s['cor2'], s['flo2']], dim=-1)                       # update.py:104 / 83
     s['mot'] = conv('encoder/conv', s['corflo'], 1)
-    x = torch.cat([inp, s['mot'], flow], dim=-1).contiguous()                      # update.py:106, 146: [inp | motion 126 | flow 2]
+    x = torch.cat([inp, s['mot'], flow], dim=-1).contiguous()                      # update.py:106, 146: [inp | motion | flow]
     s['x'] = x
     h = net
-    for g in ('1', '2'):                                                           # update.py:51-67
+    for g in cfg['gru']:                                                           # update.py:51-67 / 26-35
         kzr = _cached(w[f'{p}/gru/convz{g}/kernel'], 'kzr', lambda: np.concatenate(
             [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3))
         bzr = _cached(w[f'{p}/gru/convz{g}/bias'], 'bzr', lambda: np.concatenate(
@@ -222,7 +232,7 @@ def basic_update_block_forward(weights, net, inp, corr, flow, prefix='update_blo
         hx = torch.cat([h, x], dim=-1).contiguous()
         a_zr = _conv_fwd(hx, kzr, bzr)
         z, r, rh = (torch.empty_like(h) for _ in range(3))
-        check(lib.raft_gru_gate_zr_f32(_dev.ptr(a_zr), _dev.ptr(h), 128, M, _dev.ptr(z), _dev.ptr(r), _dev.ptr(rh),
+        check(lib.raft_gru_gate_zr_f32(_dev.ptr(a_zr), _dev.ptr(h), hd, M, _dev.ptr(z), _dev.ptr(r), _dev.ptr(rh),
                                        _dev.stream_ptr()), 'gate_zr')
         rhx = torch.cat([rh, x], dim=-1).contiguous()
         a_q = conv(f'gru/convq{g}', rhx)
@@ -234,21 +244,29 @@ def basic_update_block_forward(weights, net, inp, corr, flow, prefix='update_blo
     s['net'] = h
     s['fh'] = conv('flow_head/conv1', h, 1)
     delta = conv('flow_head/conv2', s['fh'])
-    s['m0'] = conv('mask/0', h, 1)
-    mask = conv('mask/2', s['m0'], 0, 0.25)                                        # update.py:152
-    return _dev.wrap(h), _dev.wrap(mask), _dev.wrap(delta), s
+    mask = None
+    if cfg['mask']:
+        s['m0'] = conv('mask/0', h, 1)
+        mask = _dev.wrap(conv('mask/2', s['m0'], 0, 0.25))                         # update.py:152
+    return _dev.wrap(h), mask, _dev.wrap(delta), s
 
 
-def basic_update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update_block'):
-    """Backward of ``basic_update_block_forward``: upstream gradients of its three outputs -> gradients w.r.t. the four
-    inputs (``net``, ``inp``, ``corr``, ``flow``) and w.r.t. every kernel and bias of the block (dict under the weight
-    names).  Every arithmetic step is a HIP kernel (convolution dgrad / wgrad, gate and relu backward, axpby); torch only
-    concatenates, slices and allocates."""
+def basic_update_block_forward(weights, net, inp, corr, flow, prefix='update_block'):
+    return update_block_forward(weights, net, inp, corr, flow, prefix, 'raft')
+
+
+def update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update_block'):
+    """Backward of ``update_block_forward``: upstream gradients of its outputs (``d_mask`` None for the small block) ->
+    gradients w.r.t. the four inputs (``net``, ``inp``, ``corr``, ``flow``) and w.r.t. every kernel and bias of the block
+    (dict under the weight names).  Every arithmetic step is a HIP kernel (convolution dgrad / wgrad, gate and relu backward,
+    axpby); torch only concatenates, slices and allocates."""
     lib = _dev.lib()
     p = prefix
-    w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p)}
     s = saved
-    d_net, d_mask, d_delta = (_f32(t) for t in (d_net, d_mask, d_delta))
+    cfg = _UB[s['variant']]
+    hd, cd, mot = cfg['hdim'], cfg['cdim'], cfg['mot']
+    w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p)}
+    d_net, d_delta = _f32(d_net), _f32(d_delta)
     grads = {}
     B, H, W, _ = d_net.shape
     n_h = d_net.numel()
@@ -260,24 +278,25 @@ def basic_update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='
             grads[f'{p}/{name}/kernel'], grads[f'{p}/{name}/bias'] = dk, db
         return dx, dk, db
 
-    # mask head: mask = 0.25 * mask.2(relu(mask.0(net)))                          update.py:137-141, 152
-    dm = _axpby(0.25, d_mask)
-    dm0, _, _ = conv_b('mask/2', s['m0'], dm)
-    dh_a, _, _ = conv_b('mask/0', s['net'], dm0, y=s['m0'])
+    dh = d_net
+    if cfg['mask']:   # mask = 0.25 * mask.2(relu(mask.0(net)))                   update.py:137-141, 152
+        dm = _axpby(0.25, _f32(d_mask))
+        dm0, _, _ = conv_b('mask/2', s['m0'], dm)
+        dh_a, _, _ = conv_b('mask/0', s['net'], dm0, y=s['m0'])
+        dh = _axpby(1.0, dh, 1.0, dh_a)
     # flow head: delta = conv2(relu(conv1(net)))                                  update.py:13-14
     dfh, _, _ = conv_b('flow_head/conv2', s['fh'], d_delta)
     dh_b, _, _ = conv_b('flow_head/conv1', s['net'], dfh, y=s['fh'])
-    dh = _axpby(1.0, d_net, 1.0, dh_a)
     dh = _axpby(1.0, dh, 1.0, dh_b)
     dx_total = None
-    for g in ('2', '1'):                                                           # SepConvGRU, vertical pass first
+    for g in reversed(cfg['gru']):                                                 # SepConvGRU: vertical pass first
         h_in, z, r, q = s[f'h_in{g}'], s[f'z{g}'], s[f'r{g}'], s[f'q{g}']
         dz_pre, dq_pre, dh_in = (torch.empty_like(h_in) for _ in range(3))
         check(lib.raft_gru_gate_q_backward_f32(_dev.ptr(dh), _dev.ptr(z), _dev.ptr(q), _dev.ptr(h_in), n_h, _dev.ptr(dz_pre),
                                                _dev.ptr(dq_pre), _dev.ptr(dh_in), _dev.stream_ptr()), 'gate_q_backward')
         d_rhx, _, _ = conv_b(f'gru/convq{g}', s[f'rhx{g}'], dq_pre)
-        d_rh = d_rhx[..., :128].contiguous()
-        dx_q = d_rhx[..., 128:].contiguous()
+        d_rh = d_rhx[..., :hd].contiguous()
+        dx_q = d_rhx[..., hd:].contiguous()
         dr_pre = torch.empty_like(h_in)
         check(lib.raft_gru_gate_r_backward_f32(_dev.ptr(d_rh), _dev.ptr(r), _dev.ptr(h_in), n_h, _dev.ptr(dr_pre), _dev.ptr(dh_in),
                                                _dev.stream_ptr()), 'gate_r_backward')
@@ -285,35 +304,43 @@ def basic_update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='
             [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3))
         d_zr = torch.cat([dz_pre, dr_pre], dim=-1).contiguous()
         d_hx, dk, db = conv_b(None, s[f'hx{g}'], d_zr, kernel=kzr)
-        grads[f'{p}/gru/convz{g}/kernel'], grads[f'{p}/gru/convr{g}/kernel'] = dk[..., :128].contiguous(), dk[..., 128:].contiguous()
-        grads[f'{p}/gru/convz{g}/bias'], grads[f'{p}/gru/convr{g}/bias'] = db[:128].contiguous(), db[128:].contiguous()
-        dh = _axpby(1.0, dh_in, 1.0, d_hx[..., :128].contiguous())
-        dx_g = _axpby(1.0, dx_q, 1.0, d_hx[..., 128:].contiguous())
+        grads[f'{p}/gru/convz{g}/kernel'], grads[f'{p}/gru/convr{g}/kernel'] = dk[..., :hd].contiguous(), dk[..., hd:].contiguous()
+        grads[f'{p}/gru/convz{g}/bias'], grads[f'{p}/gru/convr{g}/bias'] = db[:hd].contiguous(), db[hd:].contiguous()
+        dh = _axpby(1.0, dh_in, 1.0, d_hx[..., :hd].contiguous())
+        dx_g = _axpby(1.0, dx_q, 1.0, d_hx[..., hd:].contiguous())
         dx_total = dx_g if dx_total is None else _axpby(1.0, dx_total, 1.0, dx_g)
-    d_inp = dx_total[..., :128].contiguous()
-    d_mot = dx_total[..., 128:254].contiguous()
-    d_flow_x = dx_total[..., 254:256].contiguous()
-    # motion encoder                                                               update.py:97-106
+    d_inp = dx_total[..., :cd].contiguous()
+    d_mot = dx_total[..., cd:cd + mot].contiguous()
+    d_flow_x = dx_total[..., cd + mot:cd + mot + 2].contiguous()
+    # motion encoder                                                               update.py:97-106 / 78-85
     d_corflo, _, _ = conv_b('encoder/conv', s['corflo'], d_mot, y=s['mot'])
-    d_cor2 = d_corflo[..., :192].contiguous()
-    d_flo2 = d_corflo[..., 192:].contiguous()
-    d_cor1, _, _ = conv_b('encoder/convc2', s['cor1'], d_cor2, y=s['cor2'])
+    d_cor2 = d_corflo[..., :cfg['cor']].contiguous()
+    d_flo2 = d_corflo[..., cfg['cor']:].contiguous()
+    if cfg['convc2']:
+        d_cor1, _, _ = conv_b('encoder/convc2', s['cor1'], d_cor2, y=s['cor2'])
+    else:
+        d_cor1 = d_cor2
     d_corr, _, _ = conv_b('encoder/convc1', s['corr'], d_cor1, y=s['cor1'])
     d_flo1, _, _ = conv_b('encoder/convf2', s['flo1'], d_flo2, y=s['flo2'])
     masked = torch.empty_like(d_flo1)
     check(lib.raft_relu_backward_f32(_dev.ptr(s['flo1']), _dev.ptr(d_flo1), _dev.ptr(masked), masked.numel(), _dev.stream_ptr()),
           'relu_backward')
-    k7 = _cached(w[f'{p}/encoder/convf1/kernel'], 'k7', lambda: _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, 128)))
+    cf1 = cfg['cf1']
+    k7 = _cached(w[f'{p}/encoder/convf1/kernel'], 'k7', lambda: _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, cf1)))
     d_flow_f = torch.empty((B, H, W, 2), device=d_net.device, dtype=torch.float32)
-    dk7 = torch.empty((98, 128), device=d_net.device, dtype=torch.float32)
-    db7 = torch.empty((128,), device=d_net.device, dtype=torch.float32)
-    ws = torch.empty((int(lib.raft_conv7x7_c2_wgrad_workspace_floats(128)),), device=d_net.device, dtype=torch.float32)
-    check(lib.raft_conv7x7_c2_backward_f32(_dev.ptr(s['flow']), _dev.ptr(masked), 128, _dev.ptr(k7), 128, B, H, W, _dev.ptr(d_flow_f),
+    dk7 = torch.empty((98, cf1), device=d_net.device, dtype=torch.float32)
+    db7 = torch.empty((cf1,), device=d_net.device, dtype=torch.float32)
+    ws = torch.empty((int(lib.raft_conv7x7_c2_wgrad_workspace_floats(cf1)),), device=d_net.device, dtype=torch.float32)
+    check(lib.raft_conv7x7_c2_backward_f32(_dev.ptr(s['flow']), _dev.ptr(masked), cf1, _dev.ptr(k7), cf1, B, H, W, _dev.ptr(d_flow_f),
                                            _dev.ptr(dk7), _dev.ptr(db7), _dev.ptr(ws), _dev.stream_ptr()), 'conv7x7_c2_backward')
-    grads[f'{p}/encoder/convf1/kernel'], grads[f'{p}/encoder/convf1/bias'] = dk7.view(7, 7, 2, 128), db7
+    grads[f'{p}/encoder/convf1/kernel'], grads[f'{p}/encoder/convf1/bias'] = dk7.view(7, 7, 2, cf1), db7
     d_flow = _axpby(1.0, d_flow_x, 1.0, d_flow_f)
     return {'net': _dev.wrap(dh), 'inp': _dev.wrap(d_inp), 'corr': _dev.wrap(d_corr), 'flow': _dev.wrap(d_flow)}, \
         {k: _dev.wrap(v) for k, v in grads.items()}
+
+
+def basic_update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update_block'):
+    return update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -332,7 +359,15 @@ def upsample_flow_backward(flow, mask, d_up):
     return d_flow, d_mask
 
 
-def loop_forward(weights, corr_block, net0, inp, iters, prefix='update_block'):
+def upflow8_backward(d_up, B, h, w):
+    """Backward of ``upflow8`` (reference corr.py:93-96: 8 * half-pixel bilinear resize by 8): ``d_flow`` (B, h, w, 2)."""
+    d_up = _f32(d_up)
+    out = torch.empty((B, h, w, 2), device=d_up.device, dtype=torch.float32)
+    check(_dev.lib().raft_upflow8_backward_f32(_dev.ptr(d_up), B, h, w, _dev.ptr(out), _dev.stream_ptr()), 'upflow8_backward')
+    return out
+
+
+def loop_forward(weights, corr_block, net0, inp, iters, prefix='update_block', variant='raft'):
     """The ``for i in range(iters)`` loop of ``RAFT.call`` (reference model.py:91-109) in training form, from the correlation
     volume, ``net0 = tanh(.)`` and ``inp = relu(.)`` on: lookup -> update block -> coords1 += delta -> convex upsampling.
     Returns ``(flow_predictions, tape)``; the tape holds what ``loop_backward`` needs."""
@@ -346,13 +381,17 @@ def loop_forward(weights, corr_block, net0, inp, iters, prefix='update_block'):
     for _ in range(iters):
         corr = corr_block.retrieve(coords1).as_subclass(torch.Tensor)
         flow = _axpby(1.0, coords1, -1.0, coords0)
-        net_n, mask, delta, saved = basic_update_block_forward(weights, net, inp, corr, flow, prefix)
+        net_n, mask, delta, saved = update_block_forward(weights, net, inp, corr, flow, prefix, variant)
         coords_n = _axpby(1.0, coords1, 1.0, delta.as_subclass(torch.Tensor))
         flow_n = _axpby(1.0, coords_n, -1.0, coords0)
         up = torch.empty((B, 8 * h, 8 * w, 2), device=net.device, dtype=torch.float32)
-        check(lib.raft_upsample_convex_f32(_dev.ptr(flow_n), _dev.ptr(mask.as_subclass(torch.Tensor)), B, h, w, _dev.ptr(up),
-                                           _dev.stream_ptr()), 'upsample_convex')
-        tape.append(dict(coords1=coords1, saved=saved, flow_n=flow_n, mask=mask.as_subclass(torch.Tensor)))
+        if mask is not None:
+            mask = mask.as_subclass(torch.Tensor)
+            check(lib.raft_upsample_convex_f32(_dev.ptr(flow_n), _dev.ptr(mask), B, h, w, _dev.ptr(up), _dev.stream_ptr()),
+                  'upsample_convex')
+        else:                                                                       # SmallRAFT: model.py:223
+            check(lib.raft_upflow8_f32(_dev.ptr(flow_n), B, h, w, _dev.ptr(up), _dev.stream_ptr()), 'upflow8')
+        tape.append(dict(coords1=coords1, saved=saved, flow_n=flow_n, mask=mask))
         preds.append(_dev.wrap(up))
         net, coords1 = net_n.as_subclass(torch.Tensor), coords_n
     return preds, tape
@@ -370,11 +409,15 @@ def loop_backward(weights, corr_block, tape, d_preds, prefix='update_block'):
     wg = None
     for i in reversed(range(iters)):
         t = tape[i]
-        d_flowlow, d_mask = upsample_flow_backward(t['flow_n'], t['mask'], d_preds[i])
+        if t['mask'] is not None:
+            d_flowlow, d_mask = upsample_flow_backward(t['flow_n'], t['mask'], d_preds[i])
+        else:
+            B_, h_, w_, _ = t['flow_n'].shape
+            d_flowlow, d_mask = upflow8_backward(d_preds[i], B_, h_, w_), None
         d_c = d_flowlow if d_c is None else _axpby(1.0, d_c, 1.0, d_flowlow)
         if d_net is None:
             d_net = torch.zeros_like(t['saved']['net'])
-        din, dw = basic_update_block_backward(weights, t['saved'], d_net, d_mask, d_c, prefix)
+        din, dw = update_block_backward(weights, t['saved'], d_net, d_mask, d_c, prefix)
         d_coords, d_pyr = corr_lookup_backward(corr_block, t['coords1'], din['corr'], d_pyramid=d_pyr)
         d_c = _axpby(1.0, d_c, 1.0, din['flow'].as_subclass(torch.Tensor))
         d_c = _axpby(1.0, d_c, 1.0, d_coords.as_subclass(torch.Tensor))

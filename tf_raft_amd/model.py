@@ -328,13 +328,10 @@ class RAFT:
         backward, the loop and its backward through time; ``tf_raft_amd.training.AdamW``).  With
         ``compile(..., trainable='update_block')`` the encoders stay frozen and run on the inference kernels.
         The step is orchestrated from Python and re-packs weights on the host for every convolution call: it is the
-        functional path (parity-tested against autograd on the oracle), not yet a tuned one.  RAFT only."""
+        functional path (parity-tested against autograd on the oracle), not yet a tuned one.  RAFT and SmallRAFT."""
         from . import grad, losses
         if not hasattr(self, 'flow_metrics'):
             raise RuntimeError('call compile() before train_step()')
-        if self.variant != 'raft':
-            raise NotImplementedError('train_step (reference model.py:126-144) is built for RAFT; SmallRAFT needs the backward '
-                                      'of its 3x3 ConvGRU and of upflow8')
         if self.loss is not losses.sequence_loss:
             raise NotImplementedError('train_step differentiates tf_raft_amd.losses.sequence_loss only')
         if self.optimizer is None or not hasattr(self.optimizer, 'apply_gradients'):
@@ -363,13 +360,13 @@ class RAFT:
             cnet = self.cnet(image1, training=False, _raw_images=True)
         correlation = CorrBlock(fmap1, fmap2, num_levels=self.corr_levels, radius=self.corr_radius)   # model.py:77
         st = self._get_state(B, h, w, image1.device)
-        check(_dev.lib().raft_prepare_state_f32(_dev.ptr(cnet), st.B, st.h, st.w, C.byref(st.c), _dev.stream_ptr()),
-              'prepare_state')                                                        # model.py:84-86
+        prep = _dev.lib().raft_prepare_state_f32 if self.variant == 'raft' else _dev.lib().raft_prepare_state_small_f32
+        check(prep(_dev.ptr(cnet), st.B, st.h, st.w, C.byref(st.c), _dev.stream_ptr()), 'prepare_state')   # model.py:84-86 / 209-211
         net0 = st.net.clone()
         inp = st.x[..., :self.context_dim].contiguous()
         prefix = 'update_block'
         ub = {k: v for k, v in wts.items() if k.startswith(prefix)}
-        preds, tape = grad.loop_forward(ub, correlation, net0, inp, self.iters, prefix)
+        preds, tape = grad.loop_forward(ub, correlation, net0, inp, self.iters, prefix, self.variant)
         loss = self.loss([flow, valid], preds)
         d_preds = grad.sequence_loss_grad((flow, valid), preds)
         d_net0, d_inp, d_pyr, grads = grad.loop_backward(ub, correlation, tape, d_preds, prefix)
