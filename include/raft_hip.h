@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 208          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 209          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -243,6 +243,8 @@ typedef struct raft_basic_update_weights {
      * (84, 256, 4) -- packing.py pack_convc1_fused).  When supplied, the raft_iterate_basic_* loops on a STORED volume
      * run the lookup fused into convc1 (RAFT_LOOKUP_FUSED = 0 keeps the two kernels). */
     raft_conv_weights convc1_f;
+    /* optional: 1-D Winograd F(4, 5) transformed copies of gru_ctx1 / gru_ctx2 (8-tap kernels, with the biases) */
+    raft_conv_weights gru_ctx1_w4, gru_ctx2_w4;
 } raft_basic_update_weights;
 
 /* Device state of the recurrent loop (all caller-owned, (B*h*w) pixels, NHWC):

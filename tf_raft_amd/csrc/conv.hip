@@ -555,8 +555,15 @@ extern "C" int raft_gru_context_f32(const raft_basic_update_weights *wts, int B,
     RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
     for (int pass = 0; pass < 2; ++pass) {
         const raft_conv_weights &wc = pass == 0 ? wts->gru_ctx1 : wts->gru_ctx2;
-        ConvArgs a = conv_args(wc, st->x, XDIM, CDIM, nullptr, 0, 0, B, h, w, 3 * HDIM, st->ctx + pass * 3 * HDIM, CTX_LD);
-        RAFT_TRY(raft_launch_conv(a, pass == 0 ? 1 : 5, pass == 0 ? 5 : 1, EPI_LINEAR, (hipStream_t)stream));
+        const raft_conv_weights &w4 = pass == 0 ? wts->gru_ctx1_w4 : wts->gru_ctx2_w4;
+        const int kh = pass == 0 ? 1 : 5, kw = pass == 0 ? 5 : 1;
+        // F(4, 5) like the per-iteration GRU convolutions (same switch: bit 1 / 4 of RAFT_GRU_WINO4 = the pass)
+        const bool wino = w4.wp != nullptr && (raft_opt(RAFT_OPT_GRU_WINO4, RAFT_GRU_WINO4_DEFAULT) & (pass == 0 ? 1 : 4));
+        ConvArgs a = conv_args(wino ? w4 : wc, st->x, XDIM, CDIM, nullptr, 0, 0, B, h, w, 3 * HDIM, st->ctx + pass * 3 * HDIM, CTX_LD);
+        if (wino)
+            RAFT_TRY(raft_launch_conv_wino1d(a, kh, kw, EPI_LINEAR, (hipStream_t)stream, 4));
+        else
+            RAFT_TRY(raft_launch_conv(a, kh, kw, EPI_LINEAR, (hipStream_t)stream));
     }
     return RAFT_OK;
 }

@@ -175,7 +175,7 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     # SepConvGRU: the `inp` rows (128:256 of hx) of z / r / q go to the loop-invariant context
     # convolution gru_ctx{s} together with the biases; the per-iteration kernels keep [h | motion | flow]
     loop_rows = np.r_[0:128, 256:384]
-    ctx, gru_w, gru_w4 = [], [], []
+    ctx, ctx_w4, gru_w, gru_w4 = [], [], [], []
     for s in ('1', '2'):
         k, b = fuse_n(w, [f'{p}/gru/convz{s}', f'{p}/gru/convr{s}'])
         wp, bb, npad = pack_conv(k[:, :, loop_rows, :], np.zeros_like(b), [(128, 128), (128, 128)])
@@ -194,6 +194,8 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
         kc = np.concatenate([k, kq], axis=3)[:, :, 128:256, :]
         wp, bb, npad = pack_conv(kc, np.concatenate([b, bq]))
         ctx.append((f'gru_ctx{s}', wp, bb, npad))
+        wp, bb, npad = pack_conv_winograd1d(kc, np.concatenate([b, bq]), m=4)
+        ctx_w4.append((f'gru_ctx{s}_w4', wp, bb, npad))
     k, b = fuse_n(w, [f'{p}/flow_head/conv1', f'{p}/mask/0'])
     wp, bb, npad = pack_conv(k, b)
     out.append(('fh1_mask0', wp, bb, npad))
@@ -220,6 +222,7 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     out = out + sorted(gru_w4, key=lambda e: order4.index(e[0]))
     wp, bb, npad = pack_convc1_fused(w[f'{p}/encoder/convc1/kernel'], w[f'{p}/encoder/convc1/bias'])
     out.append(('convc1_f', wp, bb, npad))
+    out = out + ctx_w4
     return out
 
 
