@@ -36,6 +36,8 @@ def clear_pack_cache():
 def _cached(arr, tag, make, also=None):
     """``make()`` memoised on the identity of ``arr`` (and of ``also``); both are kept alive by the entry."""
     key = (id(arr), id(also), tag)
+    if len(_PACK) > 2048:                    # callers outside train_step never clear: keep the cache bounded
+        _PACK.clear()
     hit = _PACK.get(key)
     if hit is None or hit[0] is not arr or hit[1] is not also:
         hit = (arr, also, make())

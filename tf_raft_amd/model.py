@@ -34,6 +34,7 @@ import torch
 
 from . import _dev
 from . import weights as weights_mod
+from . import _ffi
 from ._ffi import check
 from .layers.corr import CorrBlock, coords_grid, upflow8
 from .layers.extractor import BasicEncoder, SmallEncoder
@@ -157,7 +158,7 @@ class RAFT:
         legacy default stream (handle 0, torch's default) cannot be captured, so when the caller is on it the loop is
         enqueued on a private stream ordered after / before the current one."""
         cur = torch.cuda.current_stream(dev)
-        if cur.cuda_stream != 0:
+        if cur.cuda_stream != 0 or _ffi.get_option('RAFT_LOOP_GRAPH') != '1':    # replay is opt-in (measured slower)
             yield
             return
         if self._loop_stream is None or self._loop_stream.device != dev:
