@@ -540,7 +540,7 @@ struct FusedLookupArgs {
     int ldo, npad, nvalid;
 };
 
-constexpr int FL_ROUNDS = 2, FL_QB = 14, FL_THREADS = 512, FL_LVLK = 84, FL_K = 4 * FL_LVLK, FL_LDA = FL_K + 4, FL_ROWS = 32;
+constexpr int FL_ROUNDS = 2, FL_QB = 14, FL_THREADS = 512, FL_LVLK = 84, FL_K = 4 * FL_LVLK, FL_LDA = FL_K + 8, FL_ROWS = 32;   // row stride 344: conflict-free b128 A-fragment reads (tools/bank_check.py lane groups; 340 is 2-way)
 
 // ABL (diagnostics, tools/fused_probe.py): 0 = the kernel; 1 = no lookup phase (A tile left zero); 2 = no MFMA phase
 template <int R, int ABL = 0>
