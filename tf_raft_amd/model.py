@@ -335,6 +335,9 @@ class RAFT:
             raise RuntimeError('call compile() before train_step()')
         if self.loss is not losses.sequence_loss:
             raise NotImplementedError('train_step differentiates tf_raft_amd.losses.sequence_loss only')
+        if self.drop_rate:
+            raise NotImplementedError('train_step with drop_rate > 0 (the Dropout layer at the encoder outputs, extractor.py:109-111, '
+                                      '127-128) is not built; the reference trains with drop_rate=0 (train_sintel.py:96)')
         if self.optimizer is None or not hasattr(self.optimizer, 'apply_gradients'):
             raise RuntimeError('compile() needs an optimizer with apply_gradients(grads, variables, clip_norm) '
                                '(tf_raft_amd.training.AdamW)')
