@@ -328,24 +328,31 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
     out[i] = s;
 }
 
-// column sums of dy: partial[blk][co] over a pixel range, then the same ordered reduction
+// column sums of dy: partial[blk][co] over a pixel range, then the same ordered reduction.  Thread = (pixel lane tid / 64,
+// channel tid % 64): 64-channel chunks, four pixels in flight per chunk, the four lanes joined through LDS in fixed order.
 __global__ void __launch_bounds__(256) bias_grad_partial_kernel(const float *__restrict__ dy, int ldy, int cout, int64_t M, int nblk,
                                                                 float *__restrict__ part) {
-    const int blk = blockIdx.x;
+    __shared__ float sh[4][64];
+    const int blk = blockIdx.x, cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
     const int64_t lo = M * blk / nblk, hi = M * (blk + 1) / nblk;
-    for (int c = threadIdx.x; c < cout; c += 256) {
+    for (int c0 = 0; c0 < cout; c0 += 64) {
+        const int c = c0 + cl;
         float s = 0.f;
-        for (int64_t m = lo; m < hi; ++m) s += dy[m * ldy + c];
-        part[(int64_t)blk * cout + c] = s;
+        if (c < cout)
+            for (int64_t m = lo + pr; m < hi; m += 4) s += dy[m * ldy + c];
+        sh[pr][cl] = s;
+        __syncthreads();
+        if (pr == 0 && c < cout) part[(int64_t)blk * cout + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        __syncthreads();
     }
 }
 
 int wgrad_slices(int cin, int cout, int B, int H, int W) {
     const int ntiles = B * ((H + WG_TH - 1) / WG_TH) * ((W + WG_TW - 1) / WG_TW);
     const int blocks = ((cin + 63) / 64) * ((cout + 63) / 64);
-    int S = (1024 + blocks - 1) / blocks;                  // about four workgroups per CU
-    if (S > ntiles) S = ntiles;
-    if (S > 128) S = 128;
+    int S = (512 + blocks - 1) / blocks;                   // about two workgroups per CU: every slice costs a pass of the
+    if (S > ntiles) S = ntiles;                            // ordered second-stage sum over the whole kernel gradient
+    if (S > 64) S = 64;
     return S < 1 ? 1 : S;
 }
 constexpr int BIAS_BLOCKS = 256;
@@ -948,7 +955,7 @@ extern "C" int raft_prepare_state_backward_f32(const float *net0, const float *i
 //   backward  dx = gamma rstd (dy - mean_P(dy) - xhat mean_P(dy xhat)),  dgamma[c] = sum dy xhat,  dbeta[c] = sum dy
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr int NORM_SLICES = 64;
+constexpr int NORM_SLICES = 256;   // workgroups per group: batch norm has ONE group over B*H*W pixels
 
 // part[(g * NORM_SLICES + s) * C + c] = {sum a, sum b} over the slice's pixels; mode 0: (x, x^2); mode 1: (dy, dy * xhat)
 __global__ void __launch_bounds__(256) norm_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mean,
