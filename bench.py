@@ -352,17 +352,25 @@ def main():
         result['pre_loop_ms'] = {k: round(v, 4) for k, v in pre_ms.items()}
         result['roofline_timing'] = 'HIP events on the launch stream, instrumented replay of the timed steps'
 
-        # ---------------- PCIe-inclusive rate (host-resident inputs), informational only
+        # ---------------- PCIe-inclusive rate (host-resident fp32 inputs), informational only: never `value`
         if world == 1:
+            from tf_raft_amd.prefetch import prefetch_to_device
             h1, h2 = img1.cpu().numpy(), img2.cpu().numpy()
-            step(h1, h2)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = max(1, min(args.steps, 3))
-            for _ in range(n):
-                step(h1, h2)
-            torch.cuda.synchronize()
-            result['value_incl_h2d'] = round(B * n / (time.perf_counter() - t0), 3)
+            n = 30                                  # batches per feed: the first upload of a feed is not hidden
+
+            def fed(feed):
+                for a, b in feed(2):
+                    step(a, b)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for a, b in feed(n):
+                    step(a, b)
+                torch.cuda.synchronize()
+                return round(B * n / (time.perf_counter() - t0), 3)
+            # pageable arrays handed straight to the model (synchronous upload in front of every step) ...
+            result['value_incl_h2d_blocking'] = fed(lambda k: ((h1, h2) for _ in range(k)))
+            # ... and through the prefetch stage: pinned staging, upload of batch i+1 under the compute of batch i
+            result['value_incl_h2d'] = fed(lambda k: prefetch_to_device(((h1, h2) for _ in range(k)), buffer_size=1))
 
         # ---------------- CPU baseline: the oracle (reference restatement) on this box's host cores
         if world == 1 and not args.no_cpu_baseline:

@@ -214,8 +214,8 @@ def test_lookup_fused_into_convc1_matches_oracle(rng, shape, sigma):
 
 
 @pytest.mark.parametrize('radius,C', [(4, 256), (3, 128)])
-# kernel: blocked MFMA (4 x 4 query blocks, default) / wave per query;  flow: smooth-ish (the bounding box of a block
-# fits) / wildly divergent (blocks fall back to one query at a time);  shapes: whole blocks / ragged edges
+# kernel: blocked MFMA (4 x 8 query blocks, default) / wave per query;  flow: smooth-ish (one bounding box of targets
+# per block) / wildly divergent (blocks fall back to one query at a time);  shapes: whole blocks / ragged edges
 @pytest.mark.parametrize('block', ['1', '0'])
 @pytest.mark.parametrize('shape,sigma', [((2, 16, 24), 4.0), ((1, 18, 21), 1.0), ((1, 16, 24), 40.0)])
 def test_corr_lookup_ondemand_matches_volume(rng, radius, C, shape, sigma, block, raft_opt):

@@ -80,6 +80,51 @@ def test_predict_step_final_only_loop_equals_last_prediction():
     np.testing.assert_array_equal(small.predict_step((i1, i2)).numpy(), small([i1, i2])[-1].numpy())
 
 
+def test_predict_feeds_host_batches_ahead_of_the_compute_stream():
+    """keras ``Model.predict`` over predict_step (reference model.py:160-166) fed the way the reference's datasets feed
+    it (uint8 batches, ``.prefetch(1)``: train_sintel.py:50-56).  The upload / download pipelining must not change a
+    bit: every pair's flow equals predict_step on that pair's batch, for a ragged last batch, for an iterable of
+    batches, and for uint8 images (cast on the device) against the same values handed over as fp32."""
+    import tf_raft_amd
+    from tf_raft_amd import weights as wm
+    from tf_raft_amd.prefetch import prefetch_to_device
+    model = tf_raft_amd.RAFT(weights=wm.init_weights('raft', seed=6, perturb=True), iters_pred=4)
+    rng = np.random.default_rng(21)
+    u1 = rng.integers(0, 256, size=(7, 64, 96, 3), dtype=np.uint8)
+    u2 = rng.integers(0, 256, size=(7, 64, 96, 3), dtype=np.uint8)
+    f1, f2 = u1.astype(np.float32), u2.astype(np.float32)
+    want = np.concatenate([model.predict_step((f1[i:i + 3], f2[i:i + 3])).numpy() for i in range(0, 7, 3)], axis=0)
+    got = model.predict([f1, f2], batch_size=3)
+    assert isinstance(got, np.ndarray) and got.shape == (7, 64, 96, 2)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(model.predict([u1, u2], batch_size=3), want)                 # bytes over PCIe
+    dataset = [(u1[i:i + 3], u2[i:i + 3], None) for i in range(0, 7, 3)]                       # (image1, image2, ...) batches
+    np.testing.assert_array_equal(model.predict(dataset), want)
+    np.testing.assert_array_equal(model.predict(dataset, steps=2), want[:6])
+    small = tf_raft_amd.SmallRAFT(iters_pred=2)
+    np.testing.assert_array_equal(small.predict([u1, u2], batch_size=4),
+                                  np.concatenate([small.predict_step((f1[:4], f2[:4])).numpy(),
+                                                  small.predict_step((f1[4:], f2[4:])).numpy()], axis=0))
+    # the prefetch stage itself: order and values preserved, dtype as handed over, buffers reused across batches
+    seen = [tuple(t.cpu().numpy() for t in b) for b in prefetch_to_device(dataset_arrays(u1, f2), buffer_size=2)]
+    assert len(seen) == 7
+    for i, (a, b) in enumerate(seen):
+        assert a.dtype == np.uint8 and b.dtype == np.float32
+        np.testing.assert_array_equal(a, u1[i:i + 1])
+        np.testing.assert_array_equal(b, f2[i:i + 1])
+    with pytest.raises(ValueError):
+        model.predict([f1, f2[:3]])
+    with pytest.raises(ValueError):
+        model.predict([])
+    with pytest.raises(ValueError):
+        list(prefetch_to_device(dataset, buffer_size=0))
+
+
+def dataset_arrays(a, b):
+    for i in range(a.shape[0]):
+        yield a[i:i + 1], b[i:i + 1]
+
+
 def test_hip_loop_is_deterministic():
     """Same feature maps, same state -> bit-identical predictions from two runs of the HIP loop."""
     import tf_raft_amd

@@ -40,6 +40,8 @@ def to_device(x, device=None, dtype=torch.float32) -> torch.Tensor:
         t = x.detach().as_subclass(torch.Tensor)
     else:
         t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    if t.device != device and t.element_size() < torch.empty((), dtype=dtype).element_size():
+        t = t.to(device=device)                 # narrow host data (uint8 images) crosses PCIe as it is; cast in HBM
     return t.to(device=device, dtype=dtype).contiguous()
 
 

@@ -91,42 +91,58 @@ __global__ void __launch_bounds__(256) corr_lookup_ondemand_kernel(OnDemandArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Blocked variant: a workgroup serves a 4 x 4 block of query pixels.  Neighbouring queries look at almost the same
-// targets, so per level the block's footprints are covered by one bounding box of targets (<= 24 rows x 32 columns
-// at the level's resolution, typically ~13 x 13) and the correlations  <fmap1[q], fmap2_l[t]>  of all 16 queries with
-// every 16-target run of a bounding-box row come out of one 16 x 16 x C fp32-MFMA tile: fmap1 of the block stays in
-// registers (lane = (query, k-quad)), a target row is read ONCE per block instead of once per query (the wave-per-
-// query kernel above moves 400 KB of fmap2 rows per query through L2: that, not arithmetic, is its limit).  The tile
-// results go to LDS as per-query correlation patches; the window evaluation is the same clamp / ceil-floor code.
-// Per level the block picks the coarsest grouping whose boxes fit: the whole block (one MFMA pass), its four 2 x 2
-// sub-blocks (four passes), or -- flow that diverges by many pixels inside 2 x 2 pixels -- the wave-wide dot products
-// of the kernel above for each query, so the worst case costs what that kernel costs.
+// Blocked variant: a workgroup serves one pyramid level of a 4 x 8 block of query pixels -- two 4 x 4 sub-blocks, two
+// waves each.  Neighbouring queries look at almost the same targets, so the block's footprints are covered by one
+// bounding box of targets (typically 13 x 17 at level 0) and the correlations  <fmap1[q], fmap2_l[t]>  of a sub-block's
+// 16 queries with 16 targets come out of one 16 x 16 x C fp32-MFMA tile: fmap1 of the sub-block stays in registers
+// (lane = (query, k-quad)) and a target row is read once per block instead of once per query (the wave-per-query
+// kernel above moves 400 KB of fmap2 rows per query through L2: that, not arithmetic, is its limit).
+//   * The union box is linearised row-major and cut into runs of 16 targets with no per-row padding.
+//   * A step stages two runs: every wave fetches 8 of the 32 rows, one whole row (C contiguous floats) per wave-wide
+//     load at a scalar row address, into registers while the previous step's MFMAs issue; between the step's two
+//     barriers the rows go to LDS (row stride C + 8 floats: the ds_read_b128 of the B-operand layout is conflict-free)
+//     and both sub-blocks take their B operand from there, the two waves of a sub-block one run each.
+//   * Only the (2r+2)^2 footprint of each query is kept (14 KB of LDS), so there is no box capacity: flow that
+//     diverges inside the block costs more runs, smoothly, and only a union box of more than MAXG runs falls back to
+//     the wave-wide dot products of the first kernel.
+//   * The window evaluation is the same clamp / ceil-floor code as the volume lookup.
+// History (profiles/r05y_ondemand_*): the first blocked kernel (4 x 4 queries per workgroup, B operand straight from
+// global memory in 64-byte pieces, bounding-box patches in 50 KB of LDS) ran its MFMA pipe 30 % busy and took the same
+// time with the MFMAs removed -- it waited for target rows, 16 KB per run, fetched by every block on its own.
 // ------------------------------------------------------------------------------------------------
 template <int R, int C>
-__global__ void __launch_bounds__(256, 2) corr_lookup_ondemand_block_kernel(OnDemandArgs p, int B, int H, int W) {
-    constexpr int D = 2 * R + 1, FW = 2 * R + 2, KQ = C / 16;      // KQ b128 per lane = all k-steps of one operand row
-    constexpr int BH = 24, BW = 32;                                  // box capacity (rows, columns): 48 KB of patches
-    constexpr int V = C / 64;                                        // channels per lane of the wave-wide dot products
-    __shared__ float sC[16][BH * BW];                                // correlation patch per query
-    __shared__ int sorg[16][2];                                      // footprint origin of every query at this level
-    __shared__ int sbox[16][2];                                      // origin of the box its patch is stored relative to
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+__global__ void __launch_bounds__(256, 3) corr_lookup_ondemand_block_kernel(OnDemandArgs p, int B, int H, int W) {
+    constexpr int D = 2 * R + 1, FW = 2 * R + 2, FWS = FW + 1, KQ = C / 16, V = C / 64;
+    constexpr int RS = C + 8;                  // staged row stride in floats
+    constexpr int LPR = C / 4;                 // lanes per staged row (16 bytes each)
+    constexpr int RPI = 64 / LPR;              // rows per wave-wide load
+    constexpr int NI = 8 / RPI;                // loads per wave per step: 8 of the step's rows
+    constexpr int NPAR = 2;                    // waves per sub-block: each takes one run of a step
+    constexpr int NT = 128 * NPAR;             // threads
+    constexpr int SROWS = 16 * NPAR;           // target rows staged per step: one run per wave pair
+    constexpr int MAXG = 96;                   // runs per level beyond which the union box is not worth staging
+    __shared__ __attribute__((aligned(16))) float sT[SROWS * RS];   // the step's target rows (NPAR runs)
+    __shared__ float sP[32][FW * FWS];         // footprint correlations of every query at this level
+    __shared__ int sorg[32][2];                // footprint origin of every query at this level
+    __shared__ int swb[2][4];                  // lo_x, lo_y, hi_x, hi_y of the two sub-blocks
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int G = lane >> 4, LR = lane & 15;
-    const int bxn = (W + 3) >> 2, byn = (H + 3) >> 2;
+    const int sb = wv & 1, par = wv >> 1;      // sub-block (left / right 4 x 4), which run of a step this wave takes
+    const int bxn = (W + 7) >> 3, byn = (H + 3) >> 2;
     const int blk = blockIdx.x;
     const int b = blk / (bxn * byn), by = (blk / bxn) % byn, bx = blk % bxn;
-    // query qi of the block: (qy, qx), clamped duplicates at ragged edges (their stores are masked)
+    // query qi = 16 * sub-block + 4 * row + column; clamped duplicates at ragged edges (their stores are masked)
     auto query_of = [&](int qi, int &qy, int &qx, bool &valid) {
-        const int yy = by * 4 + (qi >> 2), xx = bx * 4 + (qi & 3);
+        const int yy = by * 4 + ((qi & 15) >> 2), xx = bx * 8 + 4 * (qi >> 4) + (qi & 3);
         valid = yy < H && xx < W;
         qy = yy < H ? yy : H - 1;
         qx = xx < W ? xx : W - 1;
     };
     int qy, qx;
     bool qvalid;
-    query_of(LR, qy, qx, qvalid);
+    query_of(sb * 16 + LR, qy, qx, qvalid);
     const int64_t qlin = ((int64_t)b * H + qy) * W + qx;
-    // A operand: lane (query LR, k-quad G) holds channels 16 kk + 4 G .. + 3, kk = 0 .. KQ-1
+    // A operand: lane (query LR of the sub-block, k-quad G) holds channels 16 kk + 4 G .. + 3, kk = 0 .. KQ-1
     f32x4 fa[KQ];
     {
         const float *src = p.fmap1 + qlin * C + 4 * G;
@@ -136,70 +152,114 @@ __global__ void __launch_bounds__(256, 2) corr_lookup_ondemand_block_kernel(OnDe
     const float cx0 = p.coords[2 * qlin], cy0 = p.coords[2 * qlin + 1];
     const float *f2b = p.f2pyr + (int64_t)b * p.T * C;
     const float inv = 1.0f / p.sqrt_c;
+    const int srow = lane / LPR, schunk = 4 * (lane % LPR);           // this lane's place in a wave-wide row load
 
-    for (int l = 0; l < p.levels; ++l) {
+    {   // one pyramid level per workgroup (blockIdx.y): four times the workgroups to fill the chip with
+        const int l = blockIdx.y;
         const float sc = 1.0f / (float)(1 << l);
         const int w = p.lw[l], h = p.lh[l], tiles_x = p.tx[l];
-        if (tid < 16) {
-            sorg[tid][0] = axis_tap(cx0 * sc, -R, w).i0;
-            sorg[tid][1] = axis_tap(cy0 * sc, -R, h).i0;
+        {   // footprint of query LR, bounding box of the sub-block by butterfly min / max over its 16 lanes
+            const int ox = axis_tap(cx0 * sc, -R, w).i0, oy = axis_tap(cy0 * sc, -R, h).i0;
+            int lx = ox, ly = oy, hx = min(ox + FW - 1, w - 1), hy = min(oy + FW - 1, h - 1);
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                lx = min(lx, __shfl_xor(lx, m, 64));
+                ly = min(ly, __shfl_xor(ly, m, 64));
+                hx = max(hx, __shfl_xor(hx, m, 64));
+                hy = max(hy, __shfl_xor(hy, m, 64));
+            }
+            if (par == 0 && lane < 16) {
+                sorg[sb * 16 + LR][0] = ox;
+                sorg[sb * 16 + LR][1] = oy;
+            }
+            if (par == 0 && lane == 0) {
+                swb[sb][0] = lx; swb[sb][1] = ly; swb[sb][2] = hx; swb[sb][3] = hy;
+            }
         }
         __syncthreads();
-        // bounding boxes of the block and of its 2 x 2 sub-blocks (sub-block of query qi: (qi >> 3) * 2 + ((qi >> 1) & 1))
-        int lo_x[5], hi_x[5], lo_y[5], hi_y[5];
+        // read from shared memory, so workgroup-uniform: say so (readfirstlane) to keep the box arithmetic on the scalar unit
+        const int bx0 = __builtin_amdgcn_readfirstlane(min(swb[0][0], swb[1][0]));
+        const int by0 = __builtin_amdgcn_readfirstlane(min(swb[0][1], swb[1][1]));
+        const int bw = __builtin_amdgcn_readfirstlane(max(swb[0][2], swb[1][2])) - bx0 + 1;
+        const int bh = __builtin_amdgcn_readfirstlane(max(swb[0][3], swb[1][3])) - by0 + 1;
+        const int U = bw * bh, ngroups = (U + 15) >> 4;               // targets of the union box, row-major, runs of 16
+        // t / bw without the integer-division sequence: t < 16 MAXG and bw <= 16 MAXG / FW, so (t + 0.5) / bw is at least
+        // 0.5 / bw ~ 3e-3 away from an integer while the float product is within ~2e-5 of it
+        const float rbw = 1.0f / (float)bw;
+        auto row_col = [&](int t, int &ty, int &tx) {
+            ty = (int)(((float)t + 0.5f) * rbw);
+            tx = t - ty * bw;
+        };
+        // the same quotient in integers for wave-uniform t (kept on the scalar unit): m = ceil(2^20 / bw) is exact for
+        // t * (m * bw - 2^20) < 2^20, and t < 16 MAXG, bw >= FW keep t * m below 2^31
+        const unsigned mbw = ((1u << 20) + (unsigned)bw - 1u) / (unsigned)bw;
+        auto row_col_uniform = [&](int t, int &ty, int &tx) {
+            ty = (int)(((unsigned)t * mbw) >> 20);
+            tx = t - ty * bw;
+        };
+        const float *lvl = f2b + p.row_off[l] * C;
+        if (ngroups <= MAXG) {                                        // workgroup-uniform
+            // origins of the four queries whose rows this lane's accumulator holds (query 4 G + r of the sub-block)
+            int oxq[4], oyq[4];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { lo_x[k] = lo_y[k] = 1 << 30; hi_x[k] = hi_y[k] = 0; }
+            for (int r = 0; r < 4; ++r) {
+                oxq[r] = sorg[sb * 16 + 4 * G + r][0];
+                oyq[r] = sorg[sb * 16 + 4 * G + r][1];
+            }
+            const int nsteps = (ngroups + NPAR - 1) / NPAR;
+            // rows of step i: global -> registers one step ahead, registers -> LDS between the step's two barriers
+            auto prefetch = [&](int i, f32x4 (&pre)[NI]) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ox = sorg[i][0], oy = sorg[i][1];
-            const int ex = min(ox + FW - 1, w - 1), ey = min(oy + FW - 1, h - 1);
-            const int sb = ((i >> 3) << 1) | ((i >> 1) & 1);
-            lo_x[4] = min(lo_x[4], ox); hi_x[4] = max(hi_x[4], ex); lo_y[4] = min(lo_y[4], oy); hi_y[4] = max(hi_y[4], ey);
-            lo_x[sb] = min(lo_x[sb], ox); hi_x[sb] = max(hi_x[sb], ex); lo_y[sb] = min(lo_y[sb], oy); hi_y[sb] = max(hi_y[sb], ey);
-        }
-        const bool fits16 = (hi_x[4] - lo_x[4] < BW) && (hi_y[4] - lo_y[4] < BH);
-        bool fits4 = true;
+                for (int n = 0; n < NI; ++n) {
+                    const int t = min(SROWS * i + 8 * wv + n * RPI + srow, U - 1);   // the tail repeats the last target
+                    int ty, tx;
+                    if (RPI == 1) row_col_uniform(t, ty, tx);          // one row per load: the row address is wave-uniform
+                    else row_col(t, ty, tx);
+                    pre[n] = *(const f32x4 *)(lvl + (int64_t)raft_tiled_index(by0 + ty, bx0 + tx, tiles_x) * C + schunk);
+                }
+            };
+            auto step = [&](int i, f32x4 (&pre)[NI]) {
+                __syncthreads();                                      // every wave is done with the previous step's rows
 #pragma unroll
-        for (int k = 0; k < 4; ++k) fits4 = fits4 && (hi_x[k] - lo_x[k] < BW) && (hi_y[k] - lo_y[k] < BH);
-        // all three conditions are workgroup-uniform (every thread read the same 16 origins)
-        if (fits16 || fits4) {
-            const int npass = fits16 ? 1 : 4;
-            for (int pass = 0; pass < npass; ++pass) {
-                const int k = fits16 ? 4 : pass;
-                const int bx0 = lo_x[k], by0 = lo_y[k], bw = hi_x[k] - lo_x[k] + 1, bh = hi_y[k] - lo_y[k] + 1;
-                const int gx = (bw + 15) >> 4, ngroups = bh * gx;
-                const float *lvl = f2b + p.row_off[l] * C + 4 * G;
-                for (int g = wv; g < ngroups; g += 4) {
-                    const int gy = g / gx, gxx = g - gy * gx;
-                    const int yy = by0 + gy, xx = min(bx0 + gxx * 16 + LR, w - 1);
-                    const float *row = lvl + (int64_t)raft_tiled_index(yy, xx, tiles_x) * C;   // target LR of the run
-                    f32x4 fbv[KQ];
+                for (int n = 0; n < NI; ++n)
+                    *(f32x4 *)(sT + (8 * wv + n * RPI + srow) * RS + schunk) = pre[n];
+                __syncthreads();
+                if (i + 1 < nsteps) prefetch(i + 1, pre);             // in flight under this step's MFMAs
+                const int g = NPAR * i + par;
+                if (g < ngroups) {
+                    const float *brow = sT + (16 * par + LR) * RS + 4 * G;     // B operand: lane (target LR, k-quad G)
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kk = 0; kk < KQ; ++kk) fbv[kk] = *(const f32x4 *)(row + 16 * kk);
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    for (int kk = 0; kk < KQ; kk += 2) {
+                        const f32x4 fb0 = *(const f32x4 *)(brow + 16 * kk);
+                        const f32x4 fb1 = *(const f32x4 *)(brow + 16 * kk + 16);
 #pragma unroll
-                    for (int kk = 0; kk < KQ; ++kk)
+                        for (int e = 0; e < 4; ++e) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk][e], fb0[e], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk + 1][e], fb1[e], acc1, 0, 0, 0);
+                        }
+                    }
+                    // acc[r] = <query 4 G + r, target 16 g + LR>: kept where the target lies in that query's footprint
+                    const int t = 16 * g + LR;
+                    int ty, tx;
+                    row_col(t, ty, tx);
+                    if (t < U) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk][e], fbv[kk][e], acc, 0, 0, 0);
-                    // acc[r] = <query 4G + r, target LR>; a sub-block pass keeps only its own queries' rows
-                    const int col = gxx * 16 + LR;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int qi = 4 * G + r;
-                        const bool mine = fits16 || ((((qi >> 3) << 1) | ((qi >> 1) & 1)) == pass);
-                        if (mine && col < BW) sC[qi][gy * BW + col] = acc[r] * inv;
+                        for (int r = 0; r < 4; ++r) {
+                            const int fy = by0 + ty - oyq[r], fx = bx0 + tx - oxq[r];
+                            if ((unsigned)fy < (unsigned)FW && (unsigned)fx < (unsigned)FW)
+                                sP[sb * 16 + 4 * G + r][fy * FWS + fx] = (acc0[r] + acc1[r]) * inv;
+                        }
                     }
                 }
-                if (tid < 16 && (fits16 || ((((tid >> 3) << 1) | ((tid >> 1) & 1)) == pass))) {
-                    sbox[tid][0] = bx0;
-                    sbox[tid][1] = by0;
-                }
-            }
+            };
+            f32x4 pre0[NI];
+            prefetch(0, pre0);
+            for (int i = 0; i < nsteps; ++i) step(i, pre0);
         } else {
-            // wave-wide dot products, four queries per wave (the algorithm of corr_lookup_ondemand_kernel)
-            for (int k = 0; k < 4; ++k) {
-                const int qi = wv * 4 + k;
+            // wave-wide dot products, the sub-block's queries dealt to its waves (the algorithm of corr_lookup_ondemand_kernel)
+            for (int k = par; k < 16; k += NPAR) {
+                const int qi = sb * 16 + k;
                 int yq, xq;
                 bool vq;
                 query_of(qi, yq, xq, vq);
@@ -211,28 +271,24 @@ __global__ void __launch_bounds__(256, 2) corr_lookup_ondemand_block_kernel(OnDe
                     for (int v = 0; v < V; ++v) f1[v] = src[v];
                 }
                 const int ox = sorg[qi][0], oy = sorg[qi][1];
-                const float *lvl = f2b + p.row_off[l] * C + lane * V;
+                const float *lv = lvl + lane * V;
                 for (int i = 0; i < FW * FW; ++i) {
                     const int fy = i / FW, fx = i - fy * FW;
                     const int yy = min(oy + fy, h - 1), xx = min(ox + fx, w - 1);
-                    const float *row = lvl + (int64_t)raft_tiled_index(yy, xx, tiles_x) * C;
+                    const float *row = lv + (int64_t)raft_tiled_index(yy, xx, tiles_x) * C;
                     float sacc = 0.f;
 #pragma unroll
                     for (int v = 0; v < V; ++v) sacc = fmaf(f1[v], row[v], sacc);
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
-                    if (lane == 0) sC[qi][fy * BW + fx] = sacc * inv;
-                }
-                if (lane == 0) {
-                    sbox[qi][0] = ox;
-                    sbox[qi][1] = oy;
+                    if (lane == 0) sP[qi][fy * FWS + fx] = sacc * inv;
                 }
             }
         }
         __syncthreads();
-        {   // window evaluation of this level for the 16 queries, each relative to the origin of its own box
+        {   // window evaluation of this level for the 32 queries, each relative to its own footprint origin
 #pragma clang fp contract(off)
-            for (int it = tid; it < 16 * D * D; it += 256) {
+            for (int it = tid; it < 32 * D * D; it += NT) {
                 const int qi = it / (D * D), c = it - qi * (D * D);
                 const int a = c / D, bb = c - a * D;
                 int yq, xq;
@@ -242,11 +298,11 @@ __global__ void __launch_bounds__(256, 2) corr_lookup_ondemand_block_kernel(OnDe
                 const int64_t ql = ((int64_t)b * H + yq) * W + xq;
                 const float cx = p.coords[2 * ql] * sc, cy = p.coords[2 * ql + 1] * sc;
                 const AxisTap tx = axis_tap(cx, a - R, w), ty = axis_tap(cy, bb - R, h);
-                const float *f = sC[qi];
-                const int bx0 = sbox[qi][0], by0 = sbox[qi][1];
-                // clamped duplicates of a footprint (taps beyond the map edge) were stored at their clamped position
-                const int x0 = tx.i0 - bx0, x1 = tx.i1 - bx0;
-                const int y0 = (ty.i0 - by0) * BW, y1 = (ty.i1 - by0) * BW;
+                const float *f = sP[qi];
+                const int ox = sorg[qi][0], oy = sorg[qi][1];
+                // taps beyond the map edge are clamped to it, i.e. to positions inside the footprint
+                const int x0 = tx.i0 - ox, x1 = tx.i1 - ox;
+                const int y0 = (ty.i0 - oy) * FWS, y1 = (ty.i1 - oy) * FWS;
                 const float c00 = ty.w0 * tx.w0, c01 = ty.w0 * tx.w1, c10 = ty.w1 * tx.w0, c11 = ty.w1 * tx.w1;
                 float v = c00 * f[y0 + x0] + c01 * f[y0 + x1];
                 v = v + c10 * f[y1 + x0];
@@ -254,7 +310,6 @@ __global__ void __launch_bounds__(256, 2) corr_lookup_ondemand_block_kernel(OnDe
                 p.out[ql * (int64_t)p.ld_out + l * (D * D) + c] = v;
             }
         }
-        __syncthreads();
     }
 }
 
@@ -299,13 +354,13 @@ extern "C" int raft_corr_lookup_ondemand_f32(const float *fmap1, const float *fm
     hipStream_t s = (hipStream_t)stream;
     {   // blocked MFMA kernel (RAFT_ONDEMAND_BLOCK=0 selects the wave-per-query kernel below: A/B timing, parity tests)
         const bool block = raft_opt(RAFT_OPT_ONDEMAND_BLOCK, 1) != 0;
-        const int nblk = B * ((h + 3) / 4) * ((w + 3) / 4);
+        const dim3 grid(B * ((h + 3) / 4) * ((w + 7) / 8), levels);
         if (block && radius == 4 && C == 256) {
-            corr_lookup_ondemand_block_kernel<4, 256><<<nblk, 256, 0, s>>>(a, B, h, w);
+            corr_lookup_ondemand_block_kernel<4, 256><<<grid, 256, 0, s>>>(a, B, h, w);
             return raft_launch_status();
         }
         if (block && radius == 3 && C == 128) {
-            corr_lookup_ondemand_block_kernel<3, 128><<<nblk, 256, 0, s>>>(a, B, h, w);
+            corr_lookup_ondemand_block_kernel<3, 128><<<grid, 256, 0, s>>>(a, B, h, w);
             return raft_launch_status();
         }
     }

@@ -301,6 +301,71 @@ class RAFT:
             return self._forward([image1, image2], training=False, final_only=True)
         return self([image1, image2], training=False)[-1]
 
+    def predict(self, x, batch_size=None, steps=None, **kwargs):
+        """``keras.Model.predict`` over ``predict_step`` (reference model.py:160-166): the final flow of every image
+        pair as one host array ``(N, H, W, 2)``.
+
+        ``x`` is ``[image1, image2]`` (host or device arrays ``(N, H, W, 3)``, split into batches of ``batch_size``,
+        Keras' default 32) or an iterable of ``(image1, image2, ...)`` batches (the reference's ``tf.data`` datasets).
+        Host batches are uploaded one batch ahead of the compute stream and the predictions come back through pinned
+        buffers one batch behind it (``tf_raft_amd.prefetch``), so neither transfer sits on the critical path."""
+        from .prefetch import prefetch_to_device
+        dev = _dev.require_gpu()
+        arrays = isinstance(x, (list, tuple)) and len(x) == 2 and all(getattr(a, 'ndim', 0) == 4 for a in x)
+        if arrays:
+            n = x[0].shape[0]
+            if x[1].shape[0] != n:
+                raise ValueError(f'image1 and image2 hold {n} and {x[1].shape[0]} images')
+            bs = int(batch_size) if batch_size else 32
+            if bs < 1:
+                raise ValueError(f'batch_size must be >= 1, got {batch_size}')
+            batches = ((x[0][i:i + bs], x[1][i:i + bs]) for i in range(0, n, bs))
+        else:
+            batches = iter(x)
+        if steps is not None:
+            import itertools
+            batches = itertools.islice(batches, int(steps))
+        batches = ((b[0], b[1]) for b in batches)
+        down = torch.cuda.Stream(device=dev)
+        pins, landing, results = {}, [], []
+        total = n if (arrays and steps is None) else None
+        whole, filled = None, 0                  # one preallocated host array when the number of pairs is known
+
+        def collect():
+            nonlocal whole, filled
+            pin, ev = landing.pop(0)
+            ev.synchronize()
+            got = pin.numpy()
+            if total is None:
+                results.append(got.copy())
+                return
+            if whole is None:
+                whole = np.empty((total,) + got.shape[1:], got.dtype)
+            whole[filled:filled + got.shape[0]] = got
+            filled += got.shape[0]
+
+        for i, (image1, image2) in enumerate(prefetch_to_device(batches, buffer_size=1, device=dev)):
+            out = self.predict_step((image1, image2)).as_subclass(torch.Tensor)
+            cur = torch.cuda.current_stream(dev)
+            key = (i & 1, tuple(out.shape))
+            if key not in pins:
+                pins[key] = torch.empty(out.shape, dtype=out.dtype).pin_memory()
+            down.wait_stream(cur)
+            with torch.cuda.stream(down):
+                pins[key].copy_(out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(down)
+            out.record_stream(down)
+            landing.append((pins[key], ev))
+            if len(landing) > 1:
+                collect()
+        while landing:
+            collect()
+        if whole is not None:
+            return whole
+        if not results:
+            raise ValueError('predict() received no batches')
+        return np.concatenate(results, axis=0)
 
     # ---- evaluation plumbing (reference model.py:111-170)
     def compile(self, optimizer=None, clip_norm=None, loss=None, epe=None, trainable='all', **kwargs):
