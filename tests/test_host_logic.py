@@ -411,6 +411,11 @@ def test_product_path_fails_loudly_without_a_gpu():
         sequence_loss((gt, valid), [gt])
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         end_point_error((gt, valid), gt)
+    from tf_raft_amd.prefetch import prefetch_to_device                 # the upload stage has nowhere to upload to
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        next(prefetch_to_device([(gt, gt)]))
+    with pytest.raises(ValueError):
+        next(prefetch_to_device([(gt, gt)], buffer_size=0))
 
 
 def test_running_mean_mirrors_keras_mean():
