@@ -160,7 +160,7 @@ def main():
     from tf_raft_amd import _dev, _ffi
     from tf_raft_amd import weights as wm
     from tf_raft_amd.layers.corr import CorrBlock
-    from tf_raft_amd.parallel import all_gather_batch
+    from tf_raft_amd.parallel import all_gather_batch_async
 
     B = args.batch if args.batch else (4 if world == 1 else 8)
     cfg_name = 'BASELINE configs[1]' if (world == 1 and B == 4) else (
@@ -172,13 +172,20 @@ def main():
     img1 = torch.rand((B, H, W, 3), device=device, generator=gen) * 255.0
     img2 = torch.rand((B, H, W, 3), device=device, generator=gen) * 255.0
 
+    pending = []          # N > 1: the all-gather of step i's final predictions is in flight while step i + 1 computes
+
     def step(a=img1, b=img2):
         preds = model([a, b], training=False)
         if world > 1:
-            return all_gather_batch(preds[-1].as_subclass(torch.Tensor), world * B)
+            pending.append(all_gather_batch_async(preds[-1].as_subclass(torch.Tensor), world * B))
+            if len(pending) > 1:
+                return pending.pop(0).wait()
+            return None
         return preds[-1]
 
     def fence():
+        while pending:
+            pending.pop(0).wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

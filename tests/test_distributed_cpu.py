@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import ROOT
-from tf_raft_amd.parallel import all_gather_batch, predict_sharded, shard_range
+from tf_raft_amd.parallel import all_gather_batch, all_gather_batch_async, predict_sharded, shard_range
 
 
 def test_shard_range_partitions_every_total():
@@ -57,6 +57,11 @@ def _worker(rank, world, port, total, tmp):
         lo, hi = shard_range(total, rank, world)
         local = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1)
         g = all_gather_batch(local, total)
+        # the same gathers left in flight (bench.py --gpus N: step i's predictions travel while step i + 1 computes):
+        # two outstanding at once, waited in order, identical to the blocking result
+        p1 = all_gather_batch_async(local, total)
+        p2 = all_gather_batch_async(local * 2, total)
+        assert torch.equal(p1.wait(), g) and torch.equal(p2.wait(), g * 2) and p1.wait() is p1.wait()
         if rank == 0:
             np.save(os.path.join(tmp, 'last.npy'), last.numpy())
             np.save(os.path.join(tmp, 'every1.npy'), every[1].numpy())
@@ -88,6 +93,7 @@ def test_two_rank_sharded_prediction_equals_single_process(tmp_path, total):
 def test_single_process_passthrough():
     t = torch.arange(6.0).reshape(3, 2)
     assert all_gather_batch(t, 3) is t
+    assert all_gather_batch_async(t, 3).wait() is t
     out = predict_sharded(lambda inp: [inp[0] * 2, inp[0] * 3], t, t)
     np.testing.assert_array_equal(out.numpy(), (t * 3).numpy())
 

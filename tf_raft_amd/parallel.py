@@ -49,6 +49,47 @@ def all_gather_batch(local: torch.Tensor, total: int, group=None) -> torch.Tenso
     return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
 
 
+class PendingGather:
+    """An all-gather in flight (``all_gather_batch(..., async_op=True)``): the collective runs on the backend's own
+    stream next to whatever the caller enqueues afterwards; ``wait()`` makes the current stream wait for it and
+    returns the gathered batch.  Holds the send buffer alive until then."""
+
+    def __init__(self, work, out, finish, keep):
+        self._work, self._out, self._finish, self._keep = work, out, finish, keep
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            self._keep = None
+            if self._finish is not None:
+                self._out = self._finish(self._out)
+                self._finish = None
+        return self._out
+
+
+def all_gather_batch_async(local: torch.Tensor, total: int, group=None) -> PendingGather:
+    """``all_gather_batch`` without the wait: step i's predictions travel over xGMI while step i + 1 computes."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return PendingGather(None, local, None, None)
+    world = dist.get_world_size(group)
+    sizes = [hi - lo for lo, hi in (shard_range(total, r, world) for r in range(world))]
+    mx = max(sizes)
+    if local.shape[0] != sizes[dist.get_rank(group)]:
+        raise ValueError(f'local shard has {local.shape[0]} items, expected {sizes[dist.get_rank(group)]}')
+    if local.shape[0] < mx:
+        pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    local = local.contiguous()
+    if len(set(sizes)) == 1:
+        out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        work = dist.all_gather_into_tensor(out, local, group=group, async_op=True)
+        return PendingGather(work, out, None, local)
+    parts = [torch.empty_like(local) for _ in range(world)]
+    work = dist.all_gather(parts, local, group=group, async_op=True)
+    return PendingGather(work, parts, lambda ps: torch.cat([p[:n] for p, n in zip(ps, sizes)], dim=0), local)
+
+
 def predict_sharded(predict: Callable[[Sequence], List[torch.Tensor]], image1, image2, group=None,
                     gather_all_iterations: bool = False):
     """Run ``predict([image1_shard, image2_shard])`` on this rank's contiguous shard of the global

@@ -82,6 +82,29 @@ def main():
         ms = timed(run, reps)
         flops = 2.0 * B * H * W * kh * kw * cin * cout
         print(f'wino {name} tnw={tnw} B={B}: {ms*1e3:.1f} us  {flops / ms / 1e9:.1f} TFLOP/s (direct-algorithm FLOPs)')
+    elif kind == 'wino1d':
+        # python tools/one_kernel.py wino1d <gru_zr|gru_q|gru_zr_v|gru_q_v> <tnw: 0 auto, 1, 2> [B] [reps] [m: 4 or 2]
+        name, tnw = sys.argv[2], sys.argv[3]
+        B = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+        reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+        m = int(sys.argv[6]) if len(sys.argv) > 6 else 4
+        kh, kw, cin, cpad, cout = LAYERS[name]
+        assert (kh, kw) in ((1, 5), (5, 1))
+        if tnw != '0':
+            _ffi_opt('RAFT_WINO_TNW', tnw)
+        k = (rng.normal(size=(kh, kw, cin, cout)) * 0.05).astype(np.float32)
+        wp, b, npad = packing.pack_conv_winograd1d(k, np.zeros(cout, np.float32), [(cin, cpad)], m=m)
+        x = _dev.to_device(rng.normal(size=(B, H, W, cpad)).astype(np.float32))
+        wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
+        out = torch.empty((B, H, W, cout), device=x.device)
+        fn = lib.raft_conv1d_winograd4_f32 if m == 4 else lib.raft_conv1d_winograd_f32
+
+        def run():
+            check(fn(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw,
+                     npad, cout, 1, 1.0, _dev.ptr(out), cout, _dev.stream_ptr()))
+        ms = timed(run, reps)
+        flops = 2.0 * B * H * W * kh * kw * cin * cout
+        print(f'wino1d F({m},5) {name} tnw={tnw} B={B}: {ms*1e3:.1f} us  {flops / ms / 1e9:.1f} TFLOP/s (direct-algorithm FLOPs)')
     elif kind == 'lookup':
         ver = sys.argv[2]
         B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
