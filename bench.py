@@ -239,6 +239,20 @@ def main():
         torch.cuda.synchronize()
         result['batch1_ms_per_pair'] = round(1e3 * (time.perf_counter() - t0) / n, 3)
         result['batch1_pairs_per_s'] = round(n / (time.perf_counter() - t0), 3)
+        # ---------------- informational: ONE GPU at the per-GPU shape `--gpus N > 1` runs (BASELINE configs[2]: 8 pairs
+        # per GPU), so that multi-GPU lines can be set against a single-GPU number of the same per-GPU work
+        if B != 8:
+            i8a = torch.cat([img1, img1.flip(0)])[:8] if B >= 4 else img1[:1].expand(8, -1, -1, -1).contiguous()
+            i8b = torch.cat([img2, img2.flip(0)])[:8] if B >= 4 else img2[:1].expand(8, -1, -1, -1).contiguous()
+            for _ in range(2):
+                model([i8a, i8b], training=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                model([i8a, i8b], training=False)
+            torch.cuda.synchronize()
+            result['pairs_per_s_at_8_pairs_per_gpu'] = round(8 * n / (time.perf_counter() - t0), 3)
+            del i8a, i8b
 
     if rank == 0:
         # ---------------- instrumented replay: per-kernel HIP-event timing on the launch stream
