@@ -59,7 +59,9 @@ int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStrea
         if (axis == 0) return tnw == 2 ? launch_wino1d<0, 2, 2, 1, 4>(a, epi, grid, s) : launch_wino1d<0, 1, 2, 1, 4>(a, epi, grid, s);
         return tnw == 2 ? launch_wino1d<1, 2, 2, 1, 4>(a, epi, grid, s) : launch_wino1d<1, 1, 2, 1, 4>(a, epi, grid, s);
     }
-    int tnw = a.npad % 64 == 0 ? 2 : 1;
+    // F(2, 5): 64-channel workgroups only where that still leaves enough of them (a single 448 x 512 pair: 112 against 448
+    // workgroups for gru_zr -- 7.90 -> 7.48 ms per forward with the 32-channel ones, profiles/r06b_b1_options.txt)
+    int tnw = (a.npad % 64 == 0 && (int64_t)tiles_of(2) * (a.npad / 64) >= 400) ? 2 : 1;
     if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
     int tm = (int64_t)tiles_of(2) * (a.npad / (32 * tnw)) >= 400 ? 2 : 1;
     if (tm_forced == 1 || tm_forced == 2) tm = tm_forced;
