@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(256, 3) corr_lookup_ondemand_block_kernel(OnDe
     __shared__ float sP[32][FW * FWS];         // footprint correlations of every query at this level
     __shared__ int sorg[32][2];                // footprint origin of every query at this level
     __shared__ int swb[2][4];                  // lo_x, lo_y, hi_x, hi_y of the two sub-blocks
+    __shared__ float stap[32][2][D];           // clamped tap coordinate of every (query, axis, offset), minus the origin
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int G = lane >> 4, LR = lane & 15;
     const int sb = wv & 1, par = wv >> 1;      // sub-block (left / right 4 x 4), which run of a step this wave takes
@@ -171,6 +172,17 @@ __global__ void __launch_bounds__(256, 3) corr_lookup_ondemand_block_kernel(OnDe
             if (par == 0 && lane < 16) {
                 sorg[sb * 16 + LR][0] = ox;
                 sorg[sb * 16 + LR][1] = oy;
+            }
+            if (par == 0) {
+                // the reference's clamp (corr.py:41-48), once per (query, axis, offset) instead of once per window value;
+                // g - origin is exact (origin is an integer <= g), so floor / ceil / ceil-g / g-floor of the difference
+                // are bit for bit those of axis_tap on g
+                for (int k = G; k < 2 * D; k += 4) {
+                    const int axis = k >= D, d = k - axis * D - R;
+                    float g = (axis ? cy0 : cx0) * sc + (float)d;
+                    g = fminf(fmaxf(g, 0.f), (float)((axis ? h : w) - 1));
+                    stap[sb * 16 + LR][axis][k - axis * D] = g - (float)(axis ? oy : ox);
+                }
             }
             if (par == 0 && lane == 0) {
                 swb[sb][0] = lx; swb[sb][1] = ly; swb[sb][2] = hx; swb[sb][3] = hy;
@@ -296,14 +308,14 @@ __global__ void __launch_bounds__(256, 3) corr_lookup_ondemand_block_kernel(OnDe
                 query_of(qi, yq, xq, vq);
                 if (!vq) continue;
                 const int64_t ql = ((int64_t)b * H + yq) * W + xq;
-                const float cx = p.coords[2 * ql] * sc, cy = p.coords[2 * ql + 1] * sc;
-                const AxisTap tx = axis_tap(cx, a - R, w), ty = axis_tap(cy, bb - R, h);
+                const float gx = stap[qi][0][a], gy = stap[qi][1][bb];
+                const float fx0 = floorf(gx), fx1 = ceilf(gx), fy0 = floorf(gy), fy1 = ceilf(gy);
+                const float wx0 = fx1 - gx, wx1 = gx - fx0, wy0 = fy1 - gy, wy1 = gy - fy0;
                 const float *f = sP[qi];
-                const int ox = sorg[qi][0], oy = sorg[qi][1];
                 // taps beyond the map edge are clamped to it, i.e. to positions inside the footprint
-                const int x0 = tx.i0 - ox, x1 = tx.i1 - ox;
-                const int y0 = (ty.i0 - oy) * FWS, y1 = (ty.i1 - oy) * FWS;
-                const float c00 = ty.w0 * tx.w0, c01 = ty.w0 * tx.w1, c10 = ty.w1 * tx.w0, c11 = ty.w1 * tx.w1;
+                const int x0 = (int)fx0, x1 = (int)fx1;
+                const int y0 = (int)fy0 * FWS, y1 = (int)fy1 * FWS;
+                const float c00 = wy0 * wx0, c01 = wy0 * wx1, c10 = wy1 * wx0, c11 = wy1 * wx1;
                 float v = c00 * f[y0 + x0] + c01 * f[y0 + x1];
                 v = v + c10 * f[y1 + x0];
                 v = v + c11 * f[y1 + x1];
