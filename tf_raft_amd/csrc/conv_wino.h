@@ -25,6 +25,9 @@
 
 #include "conv_mfma.h"
 
+#ifndef RAFT_WINO_PF1
+#define RAFT_WINO_PF1 3
+#endif
 #ifndef RAFT_WINO_ABL
 #define RAFT_WINO_ABL 0   // tools/ablate/wino_abl.hip builds this header with pieces of the main loop switched off
 #endif
@@ -46,6 +49,12 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     constexpr int NA = (HP * QS + 255) / 256;                  // float4 items per thread per stage
     constexpr int A_BUF = HP * LDA + 4;                        // + one dummy 16-byte slot for padding items
     constexpr int BN = 32 * TNW;
+    // weight fragments are fetched PF taps ahead into a ring of NR: two taps (16 MFMAs) at TNW = 2; at TNW = 1 a tap is only
+    // four MFMAs per wave and two taps do not cover an L2 round trip when few waves share the SIMD (small batches), so
+    // the two-workgroup-per-CU variants, which have the registers, run RAFT_WINO_PF1 taps ahead and the others three
+    constexpr bool OCC3 = TNW == 1 && !SB && !PRE;             // the launch bound below
+    constexpr int PF = TNW == 2 ? 2 : (OCC3 ? 3 : RAFT_WINO_PF1);
+    constexpr int NR = PF < 4 ? 4 : 8;
     static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q,
                   "winograd kernel: linear / relu / residual / GRU gate epilogues");
     __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF];
@@ -129,7 +138,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = *(const f32x4 *)(base + j * LDA);
     };
-    f32x4 fb[4][TNW];
+    f32x4 fb[NR][TNW];
     auto frag_b = [&](int c, int t, f32x4 *bf) {
         const unsigned row = (unsigned)((t * (cin >> 2) + c * 4) * p.npad) * 16u;   // wave-uniform bytes
 #pragma unroll
@@ -144,8 +153,8 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
         for (int j = 0; j < TNW; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     gload(0);
-    frag_b(0, 0, fb[0]);
-    frag_b(0, 1, fb[1]);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) frag_b(0, t, fb[t]);
     lstore(0);
     raft_barrier_lds();
     if (nst > 1) gload(1);
@@ -206,19 +215,19 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                     else if (tx == 2) V = R[2] - R[1];
                     else V = R[1] - R[3];
                     if (!(RAFT_WINO_ABL & 1)) {
-                        if (t + 2 < 16)
-                            frag_b(c, t + 2, fb[(t + 2) & 3]);
+                        if (t + PF < 16)
+                            frag_b(c, t + PF, fb[(t + PF) & (NR - 1)]);
                         else if (more_c)
-                            frag_b(c + 1, t + 2 - 16, fb[(t + 2) & 3]);
+                            frag_b(c + 1, t + PF - 16, fb[(t + PF) & (NR - 1)]);
                     }
-                    // keep the weight fetch of tap t + 2 HERE: left alone, the scheduler sinks it next to its use to
+                    // keep the weight fetch of tap t + PF HERE: left alone, the scheduler sinks it next to its use to
                     // save registers and every tap then waits out an L2 round trip (seen in the ISA: load, s_waitcnt, mfma)
                     if (SB) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int j = 0; j < TNW; ++j)
-                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[e], fb[t & 3][j][e], acc[t][j], 0, 0, 0);
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[e], fb[t & (NR - 1)][j][e], acc[t][j], 0, 0, 0);
                 }
             }
         }

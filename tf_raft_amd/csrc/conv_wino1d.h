@@ -170,7 +170,11 @@ template <int AXIS, int TNW, int EPI, int CK = 1, int TM = 2, int MO = 2>
 __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
     static_assert(MO == 2 || (MO == 4 && CK == 2), "F(4,5) stages 32 channels per barrier");
     constexpr int NT = MO + 4;                                  // taps = inputs of one output group
-    constexpr int RING = NT == 6 ? 3 : 4;                       // weight-fragment ring; NT % RING == 0
+    // weight fragments are fetched PF taps ahead into a ring (NT % RING == 0): two taps where a tap is at least 8 MFMAs per
+    // wave, four where it is only 4 (TM = TNW = 1: the under-filled launches of small batches, where nothing else on the
+    // SIMD covers the L2 round trip -- see conv_wino.h)
+    constexpr int PF = (TM * TNW == 1) ? 4 : 2;
+    constexpr int RING = PF == 2 ? (NT == 6 ? 3 : 4) : NT;
     constexpr int TILE_H = AXIS == 0 ? 2 * TM : 2 * MO * TM, TILE_W = AXIS == 0 ? 16 * MO : 16;
     constexpr int HH = AXIS == 0 ? 2 * TM : TILE_H + 4, HWP = AXIS == 0 ? TILE_W + 4 : 16, HP = HH * HWP;   // halo tile
     constexpr bool SWZ = AXIS == 0 && MO == 4;                  // lanes step 4 pixels: pad 8 floats every 4 pixels
@@ -297,8 +301,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
             for (int j = 0; j < TNW; ++j) acc[i][t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     gload(0);
-    frag_b(0, 0, fb[0]);
-    frag_b(0, 1, fb[1]);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) frag_b(0, t, fb[t]);
     lstore(0);
     raft_barrier_lds();
     if (nst > 1) gload(1);
@@ -324,11 +328,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (RAFT_WINO1D_ABL & 1) {
-                } else if (t + 2 < NT)
-                    frag_b(c, t + 2, fb[(t + 2) % RING]);
+                } else if (t + PF < NT)
+                    frag_b(c, t + PF, fb[(t + PF) % RING]);
                 else if (more_c)
-                    frag_b(c + 1, t + 2 - NT, fb[(t + 2) % RING]);
-                __builtin_amdgcn_sched_barrier(0);   // keep the weight fetch two taps ahead (see conv_wino.h)
+                    frag_b(c + 1, t + PF - NT, fb[(t + PF) % RING]);
+                __builtin_amdgcn_sched_barrier(0);   // keep the weight fetch PF taps ahead (see conv_wino.h)
                 if ((RAFT_WINO1D_ABL & 16) && t != 0) continue;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
