@@ -28,6 +28,9 @@
 #ifndef RAFT_WINO_PF1
 #define RAFT_WINO_PF1 3
 #endif
+#ifndef RAFT_WINO_PF2
+#define RAFT_WINO_PF2 2
+#endif
 #ifndef RAFT_WINO_ABL
 #define RAFT_WINO_ABL 0   // tools/ablate/wino_abl.hip builds this header with pieces of the main loop switched off
 #endif
@@ -53,7 +56,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     // four MFMAs per wave and two taps do not cover an L2 round trip when few waves share the SIMD (small batches), so
     // the two-workgroup-per-CU variants, which have the registers, run RAFT_WINO_PF1 taps ahead and the others three
     constexpr bool OCC3 = TNW == 1 && !SB && !PRE;             // the launch bound below
-    constexpr int PF = TNW == 2 ? 2 : (OCC3 ? 3 : RAFT_WINO_PF1);
+    constexpr int PF = TNW == 2 ? RAFT_WINO_PF2 : (OCC3 ? 3 : RAFT_WINO_PF1);
     constexpr int NR = PF < 4 ? 4 : 8;
     static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q,
                   "winograd kernel: linear / relu / residual / GRU gate epilogues");
