@@ -35,12 +35,14 @@
  *   RAFT_WINO_SB        0/1  pinned weight prefetch of the F(2x2,3x3) kernel                      (default: by grid size)
  *   RAFT_WINO_CK        1/2  16 or 32 channels per barrier                                       (default: by grid size)
  *   RAFT_WINO1D_TM      1/2  half- / full-height F(2,5) tiles                                    (default: by grid size)
+ *   RAFT_WINO_KS        1/2  F(2x2,3x3) kernel: K split between two wave sets of a 512-thread workgroup (default: 2 for
+ *                            launches of fewer wave-tasks than SIMDs, i.e. single pairs)
  *   RAFT_ENC_TILE       "<th><tn>" halo tile of the encoder convolutions, e.g. 72                (default: by map height)
  *   RAFT_ENC_WINO       0/1  encoder ResBlock 3x3 layers on the F(2x2,3x3) kernel                 (default 1)
  *   RAFT_LOOKUP_FUSED   0/1  prediction loops: lookup + convc1 as two kernels / fused (raft_lookup_convc1_f32)  (default 1)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
- *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x4 query blocks on MFMA         (default 1)
+ *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)
  *   RAFT_LOOP_GRAPH     0/1  three-stream loops replayed as one hipGraph launch                  (default 0: measured
  *                       slower than stream launches on ROCm 7.2 at every batch size)
  */

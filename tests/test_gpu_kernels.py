@@ -346,7 +346,9 @@ def test_conv2d_mfma_matches_oracle(rng, ksize, tile, raft_opt):
 
 
 # kernel variants: channel blocks of 32 / 64 (TNW), pinned weight prefetch on / off (SB), 16 / 32 channels per barrier (CK)
-@pytest.mark.parametrize('variant', ['tnw1', 'tnw2', 'tnw1-sb0-ck1', 'tnw1-sb0-ck2', 'tnw1-sb1-ck1', 'tnw2-sb0'])
+# + K split between two wave sets of a 512-thread workgroup (KS: the single-pair launches), forced on and off
+@pytest.mark.parametrize('variant', ['tnw1', 'tnw2', 'tnw1-sb0-ck1', 'tnw1-sb0-ck2', 'tnw1-sb1-ck1', 'tnw2-sb0', 'tnw1-ck2-ks2',
+                                     'tnw1-ck4-ks2', 'tnw1-ck2-ks1'])
 @pytest.mark.parametrize('shape', [(2, 9, 13), (1, 8, 64), (1, 5, 35)])      # ragged tiles, exact tiles, 2 x-tiles + tail
 def test_conv2d_winograd_matches_oracle(rng, shape, variant, raft_opt):
     """Winograd F(2x2, 3x3) kernel (conv_wino.h) against the float64 direct convolution; two sources, N tail."""
@@ -354,7 +356,7 @@ def test_conv2d_winograd_matches_oracle(rng, shape, variant, raft_opt):
     from tf_raft_amd import _dev, packing
     from tf_raft_amd._ffi import check
     for part in variant.split('-'):
-        key = {'tnw': 'RAFT_WINO_TNW', 'sb': 'RAFT_WINO_SB', 'ck': 'RAFT_WINO_CK'}[part.rstrip('012')]
+        key = {'tnw': 'RAFT_WINO_TNW', 'sb': 'RAFT_WINO_SB', 'ck': 'RAFT_WINO_CK', 'ks': 'RAFT_WINO_KS'}[part.rstrip('0124')]
         raft_opt.set(key, part[-1])
     tnw = variant
     B, H, W = shape
@@ -364,7 +366,7 @@ def test_conv2d_winograd_matches_oracle(rng, shape, variant, raft_opt):
     kernel = (rng.normal(size=(3, 3, c_a + c_b, cout)) * 0.1).astype(np.float32)
     bias = rng.normal(size=(cout,)).astype(np.float32)
     srcs = []
-    pad_a = 64 if 'ck2' in variant else 48                     # 32 channels per barrier need sources in multiples of 32
+    pad_a = 64 if ('ck2' in variant or 'ck4' in variant) else 48   # 32 / 64 channels per barrier: sources in multiples of that
     for arr, cpad in ((xa, pad_a), (xb, 64)):                  # the winograd kernel walks 16-channel chunks
         buf = np.zeros((B, H, W, cpad), np.float32)
         buf[..., :arr.shape[-1]] = arr

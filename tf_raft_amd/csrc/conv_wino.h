@@ -43,13 +43,20 @@
 // per CU cover the grid anyway.
 // CK = 16-channel chunks staged per barrier (1 or 2): CK = 2 halves the barriers of the TNW = 1 kernels, whose chunks
 // are only 64 MFMAs per wave (it needs 12 more staging registers, which the TNW = 2 kernels do not have).
-template <int TNW, int EPI, int PRE = 0, int STATS = 0, int SB = 0, int CK = 1>
-__global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_wino_kernel(ConvArgs p) {
+// KS = 2 (TNW = 1, CK = 2 only): split K inside the workgroup.  512 threads; waves 0-3 take the even 16-channel chunks,
+// waves 4-7 the odd ones (the two chunks of a staged stage, side by side instead of one after the other) and the two
+// partial accumulator sets are added through LDS before the epilogue.  For launches that cannot fill the chip any other
+// way: a 16 x 16 x 4 MFMA tile is 16 Winograd tiles x 16 channels, so `conv` (128 outputs) of ONE 448 x 512 pair is 448
+// wave-tasks for 1024 SIMDs whatever the tiling, and each task's K loop is the kernel's duration.
+template <int TNW, int EPI, int PRE = 0, int STATS = 0, int SB = 0, int CK = 1, int KS = 1>
+__global__ void __launch_bounds__(256 * KS, KS == 2 ? 1 : ((TNW == 1 && !SB && !PRE) ? 3 : 2)) conv_wino_kernel(ConvArgs p) {
+    static_assert(KS == 1 || (KS == 2 && TNW == 1 && (CK == 2 || CK == 4) && !PRE && !STATS), "split-K variant: TNW = 1, CK = 2 / 4, plain epilogues");
+    constexpr int NTHR = 256 * KS;
     constexpr int RB = 2, TW = 32, TH = 2 * RB;
     constexpr int HH = TH + 2, HWP = TW + 2, HP = HH * HWP;   // 6 x 34 halo pixels
     constexpr int LDA = 16 * CK + 4;                           // floats per halo pixel in LDS (20 / 36: conflict-free)
     constexpr int QS = 4 * CK;                                 // 16-byte channel quads per halo pixel per stage
-    constexpr int NA = (HP * QS + 255) / 256;                  // float4 items per thread per stage
+    constexpr int NA = (HP * QS + NTHR - 1) / NTHR;            // float4 items per thread per stage
     constexpr int A_BUF = HP * LDA + 4;                        // + one dummy 16-byte slot for padding items
     constexpr int BN = 32 * TNW;
     // weight fragments are fetched PF taps ahead into a ring of NR: two taps (16 MFMAs) at TNW = 2; at TNW = 1 a tap is only
@@ -62,7 +69,8 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                   "winograd kernel: linear / relu / residual / GRU gate epilogues");
     __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
+    const int ks = KS == 2 ? tid >> 8 : 0;                     // which 16-channel chunk of a stage this wave multiplies
     const int G = lane >> 4, LR = lane & 15;
     const int rb = w & 1, cg = w >> 1;
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
@@ -92,7 +100,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
     int pix[NA], lds_off[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int item = tid + 256 * i;
+        const int item = tid + NTHR * i;
         const int hp = item / QS, c4 = item % QS;
         const int hy = hp / HWP, hx = hp - hy * HWP;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
@@ -157,22 +165,23 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
 
     gload(0);
 #pragma unroll
-    for (int t = 0; t < PF; ++t) frag_b(0, t, fb[t]);
+    for (int t = 0; t < PF; ++t) frag_b(ks, t, fb[t]);
     lstore(0);
     raft_barrier_lds();
     if (nst > 1) gload(1);
     // patch rows: dA holds row 0, later row 3; dB row 2; dC row 1.  Every LDS read is issued one tap row ahead of its
     // use (row 1 under the MFMAs of tap row 0, row 3 under tap row 1, the NEXT chunk's rows 0 and 2 under tap row 3).
     f32x4 dA[4], dB[4], dC[4];
-    patch_row(0, 0, 0, dA);
-    patch_row(0, 0, 2, dB);
+    patch_row(0, ks, 0, dA);
+    patch_row(0, ks, 2, dB);
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
         const bool more = st + 1 < nst;
 #pragma unroll
-        for (int sub = 0; sub < CK; ++sub) {
+        for (int sub0 = 0; sub0 < CK / KS; ++sub0) {
+            const int sub = sub0 * KS + ks;                       // KS = 2: wave set ks takes the chunks ks, ks + 2, ..
             const int c = st * CK + sub;                          // 16-channel chunk index (weights)
-            const bool last_sub = sub == CK - 1;
+            const bool last_sub = sub0 == CK / KS - 1;
             const bool more_c = more || !last_sub;                // another 16-channel chunk follows
 #pragma unroll
             for (int ty = 0; ty < 4; ++ty) {
@@ -200,12 +209,12 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                         }
                         raft_barrier_lds();
                         if (more) {
-                            patch_row(buf ^ 1, 0, 0, dA);
-                            patch_row(buf ^ 1, 0, 2, dB);
+                            patch_row(buf ^ 1, ks, 0, dA);
+                            patch_row(buf ^ 1, ks, 2, dB);
                         }
                     } else {
-                        patch_row(buf, sub + 1, 0, dA);
-                        patch_row(buf, sub + 1, 2, dB);
+                        patch_row(buf, sub + KS, 0, dA);
+                        patch_row(buf, sub + KS, 2, dB);
                     }
                 }
 #pragma unroll
@@ -221,7 +230,7 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                         if (t + PF < 16)
                             frag_b(c, t + PF, fb[(t + PF) & (NR - 1)]);
                         else if (more_c)
-                            frag_b(c + 1, t + PF - 16, fb[(t + PF) & (NR - 1)]);
+                            frag_b(c + KS, t + PF - 16, fb[(t + PF) & (NR - 1)]);
                     }
                     // keep the weight fetch of tap t + PF HERE: left alone, the scheduler sinks it next to its use to
                     // save registers and every tap then waits out an L2 round trip (seen in the ISA: load, s_waitcnt, mfma)
@@ -234,6 +243,27 @@ __global__ void __launch_bounds__(256, (TNW == 1 && !SB && !PRE) ? 3 : 2) conv_w
                 }
             }
         }
+    }
+
+    if (KS == 2) {
+        // add the odd-chunk partial sums (waves 4-7) to the even-chunk ones (waves 0-3): 8 taps at a time through the
+        // staging buffers, [tap][wave][lane] float4 (conflict-free); waves 4-7 are done afterwards
+        static_assert(KS == 1 || 8 * 4 * 64 * 4 <= 2 * A_BUF, "split-K reduction buffer must fit the staging buffers");
+        f32x4 *red = (f32x4 *)smem;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            raft_barrier_lds();                                   // staging buffers / previous half no longer read
+            if (ks == 1) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) red[(t * 4 + w) * 64 + lane] = acc[8 * half + t][0];
+            }
+            raft_barrier_lds();
+            if (ks == 0) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[8 * half + t][0] += red[(t * 4 + w) * 64 + lane];
+            }
+        }
+        if (ks == 1) return;
     }
 
     // ---- epilogue: lane owns channel n; register r of an accumulator is tile m = 4G + r of the row block

@@ -25,6 +25,24 @@ static int launch_wino(const ConvArgs &a, int epi, int grid, hipStream_t s) {
     return raft_launch_status();
 }
 
+// split-K inside the workgroup (conv_wino.h, KS = 2): 512 threads, plain epilogues only; CK = 32 or 64 channels per stage
+template <int CK>
+static int launch_wino_ks2(const ConvArgs &a, int epi, int grid, hipStream_t s) {
+    if (epi == EPI_LINEAR)
+        conv_wino_kernel<1, EPI_LINEAR, 0, 0, 1, CK, 2><<<grid, 512, 0, s>>>(a);
+    else if (epi == EPI_RELU)
+        conv_wino_kernel<1, EPI_RELU, 0, 0, 1, CK, 2><<<grid, 512, 0, s>>>(a);
+    else if (epi == EPI_RES)
+        conv_wino_kernel<1, EPI_RES, 0, 0, 1, CK, 2><<<grid, 512, 0, s>>>(a);
+    else if (epi == EPI_GRU_ZR)
+        conv_wino_kernel<1, EPI_GRU_ZR, 0, 0, 1, CK, 2><<<grid, 512, 0, s>>>(a);
+    else if (epi == EPI_GRU_Q)
+        conv_wino_kernel<1, EPI_GRU_Q, 0, 0, 1, CK, 2><<<grid, 512, 0, s>>>(a);
+    else
+        return RAFT_E_UNSUPPORTED;
+    return raft_launch_status();
+}
+
 int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s) {
     if (a.c0 <= 0 || a.c0 % 16 || a.c1 < 0 || a.c1 % 16 || a.npad <= 0 || a.npad % 32) return RAFT_E_UNSUPPORTED;
     if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
@@ -48,6 +66,15 @@ int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s) {
     // 32 channels per barrier at TNW = 1 when the channel counts allow it (RAFT_WINO_CK = 1 / 2 overrides)
     const bool ck2_ok = a.c0 % 32 == 0 && a.c1 % 32 == 0;
     const bool ck2 = ck2_ok && raft_opt(RAFT_OPT_WINO_CK, grid <= 512 ? 2 : 1) == 2;   // 58 KB of LDS: two workgroups per CU
+    // fewer wave-tasks than SIMDs (grid * 4 < 1024): split K between two wave sets of a 512-thread workgroup
+    // (RAFT_WINO_KS = 1 / 2 overrides)
+    const bool plain = a.pre_scale == nullptr && a.stats == nullptr;
+    const int ks = raft_opt(RAFT_OPT_WINO_KS, (tnw == 1 && grid <= 224) ? 2 : 1);
+    if (ks == 2 && tnw == 1 && ck2_ok && plain) {
+        // 64 channels per stage where the channel counts allow: the stages of these launches are latency, not work
+        const bool ck4 = a.c0 % 64 == 0 && a.c1 % 64 == 0 && raft_opt(RAFT_OPT_WINO_CK, 4) == 4;
+        return ck4 ? launch_wino_ks2<4>(a, epi, grid, s) : launch_wino_ks2<2>(a, epi, grid, s);
+    }
     if (tnw == 2) return sb ? launch_wino<2, 1, 1>(a, epi, grid, s) : launch_wino<2, 0, 1>(a, epi, grid, s);
     if (ck2) return sb ? launch_wino<1, 1, 2>(a, epi, grid, s) : launch_wino<1, 0, 2>(a, epi, grid, s);
     return sb ? launch_wino<1, 1, 1>(a, epi, grid, s) : launch_wino<1, 0, 1>(a, epi, grid, s);
