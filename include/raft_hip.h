@@ -33,7 +33,7 @@
  *   RAFT_GRU_WINO4      the same mask for F(4,5), preferred where both bits are set              (default 15)
  *   RAFT_WINO_TNW       1/2  32- or 64-channel workgroups of the Winograd kernels                (default: by grid size)
  *   RAFT_WINO_SB        0/1  pinned weight prefetch of the F(2x2,3x3) kernel                      (default: by grid size)
- *   RAFT_WINO_CK        1/2  16 or 32 channels per barrier                                       (default: by grid size)
+ *   RAFT_WINO_CK        1/2  16 or 32 channels per barrier (4: 64, split-K kernel only)          (default: by grid size)
  *   RAFT_WINO1D_TM      1/2  half- / full-height F(2,5) tiles                                    (default: by grid size)
  *   RAFT_WINO_KS        1/2  F(2x2,3x3) kernel: K split between two wave sets of a 512-thread workgroup (default: 2 for
  *                            launches of fewer wave-tasks than SIMDs, i.e. single pairs)

@@ -112,6 +112,12 @@ def test_predict_feeds_host_batches_ahead_of_the_compute_stream():
         assert a.dtype == np.uint8 and b.dtype == np.float32
         np.testing.assert_array_equal(a, u1[i:i + 1])
         np.testing.assert_array_equal(b, f2[i:i + 1])
+    # a tensor that already lives on the device goes through untouched (no download / re-upload)
+    d1 = torch.as_tensor(f1[:2]).cuda()
+    (r1, r2), = list(prefetch_to_device([(d1, u2[:2])]))
+    assert r1.data_ptr() == d1.data_ptr() and r2.dtype == torch.uint8 and r2.is_cuda
+    np.testing.assert_array_equal(model.predict([d1, torch.as_tensor(f2[:2]).cuda()], batch_size=2),
+                                  model.predict_step((f1[:2], f2[:2])).numpy())
     with pytest.raises(ValueError):
         model.predict([f1, f2[:3]])
     with pytest.raises(ValueError):

@@ -36,10 +36,14 @@ class _Slot:
         return self.pins
 
 
-def _as_host_arrays(batch) -> Tuple[np.ndarray, ...]:
+def _as_host_arrays(batch, device) -> tuple:
+    """Host arrays of a batch as contiguous NumPy arrays; tensors that already live on ``device`` pass through untouched."""
     out = []
     for a in batch:
         if isinstance(a, torch.Tensor):
+            if a.device == device:
+                out.append(a.detach())
+                continue
             a = a.detach().cpu().numpy()
         a = np.ascontiguousarray(np.asarray(a))
         if a.dtype == np.float64:
@@ -57,7 +61,7 @@ def prefetch_to_device(batches: Iterable, buffer_size: int = 1, device=None) -> 
     copy_stream = torch.cuda.Stream(device=device)
     slots = [_Slot() for _ in range(buffer_size + 1)]
     it = iter(batches)
-    pending = []                                          # (device tensors, upload-finished event), oldest first
+    pending = []                                          # (device tensors, upload-finished event, resident flags), oldest first
     n = 0
 
     def issue() -> bool:
@@ -68,23 +72,26 @@ def prefetch_to_device(batches: Iterable, buffer_size: int = 1, device=None) -> 
             return False
         slot = slots[n % len(slots)]
         n += 1
-        pins = slot.stage(_as_host_arrays(batch))
+        arrays = _as_host_arrays(batch, device)
+        host = [a for a in arrays if not isinstance(a, torch.Tensor)]
+        pins = iter(slot.stage(host))
         with torch.cuda.stream(copy_stream):
-            dev = tuple(p.to(device, non_blocking=True) for p in pins)
+            dev = tuple(a if isinstance(a, torch.Tensor) else next(pins).to(device, non_blocking=True) for a in arrays)
             ev = torch.cuda.Event()
             ev.record(copy_stream)
         slot.done = ev
-        pending.append((dev, ev))
+        pending.append((dev, ev, tuple(isinstance(a, torch.Tensor) for a in arrays)))
         return True
 
     for _ in range(buffer_size):
         if not issue():
             break
     while pending:
-        dev, ev = pending.pop(0)
+        dev, ev, resident = pending.pop(0)
         issue()                                           # the upload of the next batch overlaps this batch's compute
         cur = torch.cuda.current_stream(device)
         cur.wait_event(ev)
-        for t in dev:
-            t.record_stream(cur)                          # allocated on the copy stream, consumed on this one
+        for t, was_resident in zip(dev, resident):
+            if not was_resident:
+                t.record_stream(cur)                      # allocated on the copy stream, consumed on this one
         yield tuple(_dev.wrap(t) for t in dev)
