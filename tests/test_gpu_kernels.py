@@ -217,7 +217,8 @@ def test_lookup_fused_into_convc1_matches_oracle(rng, shape, sigma):
 # kernel: blocked MFMA (4 x 8 query blocks, default) / wave per query;  flow: smooth-ish (one bounding box of targets
 # per block) / wildly divergent (blocks fall back to one query at a time);  shapes: whole blocks / ragged edges
 @pytest.mark.parametrize('block', ['1', '0'])
-@pytest.mark.parametrize('shape,sigma', [((2, 16, 24), 4.0), ((1, 18, 21), 1.0), ((1, 16, 24), 40.0)])
+# (1, 48, 64) at sigma 30: union boxes of more than 96 runs -> the per-query fallback inside the blocked kernel, both (r, C)
+@pytest.mark.parametrize('shape,sigma', [((2, 16, 24), 4.0), ((1, 18, 21), 1.0), ((1, 16, 24), 40.0), ((1, 48, 64), 30.0)])
 def test_corr_lookup_ondemand_matches_volume(rng, radius, C, shape, sigma, block, raft_opt):
     from tf_raft_amd.layers.corr import CorrBlock
     raft_opt.set('RAFT_ONDEMAND_BLOCK', block)
