@@ -294,13 +294,32 @@ def main():
         # roofline entries name); the product loop runs them fused (RAFT_LOOKUP_FUSED, default on), timed separately
         _ffi.set_option('RAFT_LOOKUP_FUSED', 0)
         per_launch_ms = timed_replay()
+        # What an event bracket adds to every stage: the SAME single-stream launches without events in between
+        # (raft_iterate_basic_f32), timed with one event pair, against the sum of the 14 bracketed stages.  An event record
+        # between two kernels keeps the second one from being dispatched under the first one's tail; rocprofv3's kernel
+        # durations of the single-stream loop (profiles/) agree with the stage times once this is taken off.
+        plain = []
+        for _ in range(reps + 1):
+            model._prepare(cnet, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _ffi.check(_dev.lib().raft_iterate_basic_f32(
+                C.byref(model.update_block.c), _dev.ptr(corr._pyr), corr._off, B, h, w, ITERS, C.byref(st.c),
+                _dev.ptr(flow_up), _dev.stream_ptr()), 'iterate_basic')
+            e1.record()
+            torch.cuda.synchronize()
+            plain.append(e0.elapsed_time(e1) / ITERS)
+        plain_iter_ms = float(np.median(plain[1:]))
+        bracket_ms = max(0.0, (float(per_launch_ms.sum()) - plain_iter_ms) / len(STAGES))
         _ffi.set_option('RAFT_LOOKUP_FUSED', None)
         fused_ms = timed_replay()
-        stage_ms = {k: round(float(v), 5) for k, v in zip(STAGES, per_launch_ms)}
+        stage_ms_events = {k: round(float(v), 5) for k, v in zip(STAGES, per_launch_ms)}
+        stage_ms = {k: round(max(float(v) - bracket_ms, 1e-6), 5) for k, v in zip(STAGES, per_launch_ms)}
         acc = per_launch_ms
         flops, bytes_ = stage_work(B, h, w)
         dom = STAGES[int(np.argmax(acc))]
-        fused_us = float(fused_ms[0] + fused_ms[1]) * 1e3            # lookup stage (empty) + convc1 stage (fused kernel)
+        # lookup stage (empty bracket) + convc1 stage (the fused kernel): two brackets around one kernel
+        fused_us = max(float(fused_ms[0] + fused_ms[1] - 2 * bracket_ms), 1e-3) * 1e3
         copy_gbs = measured_copy_gbs(device, _dev.lib(), _dev, _ffi.check)
         result['hbm_copy_gbs_measured'] = round(copy_gbs, 1)
 
@@ -312,7 +331,8 @@ def main():
             tr, note = pmc_traffic(dom, B)
             roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': tr,
-                    'flops_per_launch': flops[dom] / ratio, 'ms_per_launch': stage_ms[dom], 'traffic_source': note,
+                    'flops_per_launch': flops[dom] / ratio, 'ms_per_launch': stage_ms[dom],
+                    'ms_per_launch_between_events': stage_ms_events[dom], 'traffic_source': note,
                     'flops_counted': 'executed on the MFMA pipe'}
             if ratio != 1.0:
                 roof['algorithm'] = WINOGRAD_ALGORITHMS[ratio]
@@ -324,7 +344,8 @@ def main():
             tr, note = pmc_traffic(dom, B)
             roof = {'kernel': dom, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': tr,
-                    'bytes_per_launch': bytes_[dom], 'ms_per_launch': stage_ms[dom], 'traffic_source': note}
+                    'bytes_per_launch': bytes_[dom], 'ms_per_launch': stage_ms[dom],
+                    'ms_per_launch_between_events': stage_ms_events[dom], 'traffic_source': note}
         result['roofline'] = roof
         # the HBM-bound kernels the north star singles out: per-launch algorithmic bytes / HIP-event time, against the
         # 8 TB/s datasheet peak (frac) and against this box's measured copy bandwidth (frac_of_measured_copy)
@@ -335,7 +356,7 @@ def main():
                 'kernel': name, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                 'frac': round(gbs / PEAK_HBM_GBS, 4), 'frac_of_measured_copy': round(gbs / copy_gbs, 4),
                 'traffic': tr, 'bytes_per_launch': bytes_[name], 'ms_per_launch': stage_ms[name],
-                'traffic_source': note}
+                'ms_per_launch_between_events': stage_ms_events[name], 'traffic_source': note}
         # The product loop runs the lookup INSIDE convc1 (raft_lookup_convc1_f32): what the lookup costs there is the fused
         # kernel's time minus the stand-alone convc1's, for the same algorithmic bytes MINUS the 324-channel output that
         # is no longer written or re-read.
@@ -370,8 +391,14 @@ def main():
             / (mfma_ms * 1e-3) / 1e12, 2)
         result['winograd_layers'] = {k: WINOGRAD_ALGORITHMS[wl[k]] for k in sorted(wl)}
         result['stage_ms'] = stage_ms
+        result['stage_ms_between_events'] = stage_ms_events
+        result['event_bracket_us'] = round(bracket_ms * 1e3, 3)
+        result['single_stream_iteration_ms'] = {'sum_of_bracketed_stages': round(float(per_launch_ms.sum()), 5),
+                                                'same_launches_without_events': round(plain_iter_ms, 5)}
         result['pre_loop_ms'] = {k: round(v, 4) for k, v in pre_ms.items()}
-        result['roofline_timing'] = 'HIP events on the launch stream, instrumented replay of the timed steps'
+        result['roofline_timing'] = ('HIP events on the launch stream, instrumented replay of the timed steps; per-stage '
+                                     'times = interval between events minus event_bracket_us (calibrated in the same run against '
+                                     'the un-bracketed single-stream loop: the net stages add up to its measured iteration time)')
 
         # ---------------- PCIe-inclusive rate (host-resident fp32 inputs), informational only: never `value`
         if world == 1:

@@ -8,3 +8,7 @@ print('pre_loop_ms', d.get('pre_loop_ms'), 'update executed TF', d.get('update_b
 for k in ('roofline', 'roofline_corr_lookup', 'roofline_corr_build'):
     r = d.get(k, {})
     print(k, r.get('kernel'), r.get('achieved'), r.get('unit'), 'frac', r.get('frac'), 'traffic', r.get('traffic'))
+if 'event_bracket_us' in d:
+    print('event bracket us', d['event_bracket_us'], d.get('single_stream_iteration_ms'),
+          'lookup frac of copy', d['roofline_corr_lookup'].get('frac_of_measured_copy'),
+          'upsample frac of copy', d.get('roofline_upsample_convex', {}).get('frac_of_measured_copy'))
