@@ -3,8 +3,10 @@
 // Average pooling over the target dims commutes with the dot product, so level l of the
 // reference's pyramid (corr.py:106-114) equals <fmap1[q], avgpool_l(fmap2)[t]> / sqrt(C).  For each
 // query pixel the (2r+2)^2 footprint correlations of every level are computed from fmap1[q] and the
-// pooled fmap2 pyramid (raft_fmap_pyramid_f32) with wave-wide dot products, staged in LDS, and the
-// window is then evaluated exactly like the volume lookup (same clamp / ceil-floor semantics,
+// pooled fmap2 pyramid (raft_fmap_pyramid_f32) -- on fp32 MFMA for 4 x 8 blocks of queries (the default
+// kernel, second half of this file), or with wave-wide dot products one query at a time (first kernel:
+// other (radius, C) instances, A/B timing, and the fallback inside the blocked kernel) -- staged in LDS,
+// and the window is then evaluated exactly like the volume lookup (same clamp / ceil-floor semantics,
 // reference corr.py:116-152, 28-69).  The reference has no such path (README.md:109); this is the
 // high-resolution configuration of BASELINE.json (1024x1024: the volume would be 1.43 GB / pair).
 #include <stdlib.h>
