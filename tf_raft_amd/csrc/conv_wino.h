@@ -49,7 +49,7 @@
 // way: a 16 x 16 x 4 MFMA tile is 16 Winograd tiles x 16 channels, so `conv` (128 outputs) of ONE 448 x 512 pair is 448
 // wave-tasks for 1024 SIMDs whatever the tiling, and each task's K loop is the kernel's duration.
 template <int TNW, int EPI, int PRE = 0, int STATS = 0, int SB = 0, int CK = 1, int KS = 1>
-__global__ void __launch_bounds__(256 * KS, KS == 2 ? 1 : ((TNW == 1 && !SB && !PRE) ? 3 : 2)) conv_wino_kernel(ConvArgs p) {
+__global__ void __launch_bounds__(256 * KS, KS == 2 ? 1 : ((TNW == 1 && !SB && !PRE && CK == 1) ? 3 : 2)) conv_wino_kernel(ConvArgs p) {
     static_assert(KS == 1 || (KS == 2 && TNW == 1 && (CK == 2 || CK == 4) && !PRE && !STATS), "split-K variant: TNW = 1, CK = 2 / 4, plain epilogues");
     constexpr int NTHR = 256 * KS;
     constexpr int RB = 2, TW = 32, TH = 2 * RB;
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256 * KS, KS == 2 ? 1 : ((TNW == 1 && !SB && !
     // weight fragments are fetched PF taps ahead into a ring of NR: two taps (16 MFMAs) at TNW = 2; at TNW = 1 a tap is only
     // four MFMAs per wave and two taps do not cover an L2 round trip when few waves share the SIMD (small batches), so
     // the two-workgroup-per-CU variants, which have the registers, run RAFT_WINO_PF1 taps ahead and the others three
-    constexpr bool OCC3 = TNW == 1 && !SB && !PRE;             // the launch bound below
+    constexpr bool OCC3 = TNW == 1 && !SB && !PRE && CK == 1;  // the three-workgroups-per-CU launch bound above
     constexpr int PF = TNW == 2 ? RAFT_WINO_PF2 : (OCC3 ? 3 : RAFT_WINO_PF1);
     constexpr int NR = PF < 4 ? 4 : 8;
     static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q,
