@@ -1,0 +1,79 @@
+"""bench.py's roofline denominators against the hot-path contract; host-only, no GPU.
+
+The per-unit figures (one image pair at 448 x 512, fp32) are the contract's: corr_lookup 10.4 MB / iteration / pair,
+upsample_convex 10.1 MB / iteration / pair, update block 3,118,336 MAC / pixel = 22.35 GFLOP / iteration / pair.  The
+bench multiplies them by the pairs per launch; these tests keep the two in step and pin the bookkeeping around them
+(Winograd multiply ratios, the scaling of the committed PMC pass to the run's batch)."""
+import json
+import os
+
+import pytest
+
+import bench
+
+
+def test_algorithmic_work_per_launch_is_the_contract_times_the_batch():
+    h, w = bench.H // 8, bench.W // 8
+    assert (h, w) == (56, 64)
+    flops1, bytes1 = bench.stage_work(1, h, w)
+    flops4, bytes4 = bench.stage_work(4, h, w)
+    n = h * w
+    # lookup = 4 levels x N x (2r+2)^2 x 4 B read + coords + N x 324 x 4 B written = 10.4 MB / iter / pair
+    assert bytes1['corr_lookup'] == n * (4 * 100 * 4 + 8 + 324 * 4)
+    assert bytes1['corr_lookup'] / 1e6 == pytest.approx(10.4, abs=0.05)
+    # upsample: mask 576 + flow 2 floats read, 8 x 8 x 2 floats written per coarse pixel = 10.1 MB / iter / pair
+    assert bytes1['upsample_convex'] / 1e6 == pytest.approx(10.1, abs=0.05)
+    # update block: 3,118,336 MAC / px, of which the loop-invariant GRU context rows (4 x 5 x 128 x {256, 128, 256, 128}
+    # = 491,520 MAC / px) are evaluated once per forward, not per iteration
+    macs_per_px = sum(flops1.values()) / (2.0 * n)
+    assert macs_per_px + 5 * 128 * (256 + 128 + 256 + 128) == 3118336
+    assert 2 * 3118336 * n / 1e9 == pytest.approx(22.35, abs=0.01)
+    for k in flops1:                                            # per launch = per pair x pairs per launch
+        assert flops4[k] == 4 * flops1[k]
+    for k in bytes1:
+        assert bytes4[k] == 4 * bytes1[k]
+    assert set(flops1) | set(bytes1) == set(bench.STAGES)       # every stage of the loop is priced exactly once
+    assert not set(flops1) & set(bytes1)
+
+
+def test_winograd_layers_follow_the_library_switches():
+    """roofline.achieved counts EXECUTED MFMA FLOPs: direct FLOPs / {2.25, 2.5, 10/6} for the layers that are on a Winograd
+    kernel under the current switches, so that frac <= 1 (the headline frac was 1.30)."""
+    from tf_raft_amd import _ffi
+    saved = {k: _ffi.get_option(k) for k in ('RAFT_CONV_WINO', 'RAFT_GRU_WINO', 'RAFT_GRU_WINO4')}
+    try:
+        for k in saved:
+            _ffi.set_option(k, None)
+        d = bench.winograd_layers()
+        assert d == {'convc2': 2.25, 'conv': 2.25, 'fh1_mask0': 2.25, 'gru_zr1': 2.5, 'gru_q1': 2.5, 'gru_zr2': 2.5,
+                     'gru_q2': 2.5}
+        _ffi.set_option('RAFT_GRU_WINO4', 0)
+        assert bench.winograd_layers()['gru_zr1'] == pytest.approx(10.0 / 6.0)
+        _ffi.set_option('RAFT_GRU_WINO', 0)
+        _ffi.set_option('RAFT_CONV_WINO', 8)
+        assert bench.winograd_layers() == {'fh1_mask0': 2.25}
+        assert set(bench.WINOGRAD_ALGORITHMS) == {2.25, 2.5, 10.0 / 6.0}
+    finally:
+        for k, v in saved.items():
+            _ffi.set_option(k, v if v != '' else None)
+
+
+def test_pmc_traffic_scales_the_committed_pass_per_pair():
+    """`traffic` = HBM bytes per launch from the committed in-loop PMC pass (profiles/pmc_traffic.json), per pair x the
+    run's batch; the pass must be the in-loop B >= 8 one the round-1 review asked for and cover every roofline kernel."""
+    with open(os.path.join(bench.ROOT, 'profiles', 'pmc_traffic.json')) as f:
+        table = json.load(f)
+    for kernel in ('fh1_mask0', 'corr_lookup', 'upsample_convex', 'corr_build'):
+        entry = table[kernel]
+        assert entry['batch'] >= 8
+        tr4, note = bench.pmc_traffic(kernel, 4)
+        tr8, _ = bench.pmc_traffic(kernel, 8)
+        assert tr8 == pytest.approx(entry['hbm_bytes_per_launch'] * 8 / entry['batch'], abs=1)
+        assert tr4 == pytest.approx(tr8 / 2, abs=1)
+        assert note['pass_batch'] == entry['batch'] and note['scaled_to_batch'] == 4
+        if kernel != 'corr_build':
+            assert note['in_loop'] is True
+        # traffic never below the algorithmic bytes of the kernel (a pass that under-counts would flatter the kernel)
+        assert note['hbm_bytes_per_pair'] >= 0.99 * note['algorithmic_bytes_per_pair']
+    assert bench.pmc_traffic('no_such_kernel', 4) == (None, None)
+    assert bench.PEAK_FP32_MFMA_TFLOPS == 157.3 and bench.PEAK_HBM_GBS == 8000.0
