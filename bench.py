@@ -160,7 +160,7 @@ def main():
     from tf_raft_amd import _dev, _ffi
     from tf_raft_amd import weights as wm
     from tf_raft_amd.layers.corr import CorrBlock
-    from tf_raft_amd.parallel import all_gather_batch_async
+    from tf_raft_amd.parallel import all_gather_batch, all_gather_batch_async
 
     B = args.batch if args.batch else (4 if world == 1 else 8)
     cfg_name = 'BASELINE configs[1]' if (world == 1 and B == 4) else (
@@ -173,11 +173,20 @@ def main():
     img2 = torch.rand((B, H, W, 3), device=device, generator=gen) * 255.0
 
     pending = []          # N > 1: the all-gather of step i's final predictions is in flight while step i + 1 computes
+    gather_async = [os.environ.get('RAFT_BENCH_BLOCKING_GATHER', '0') != '1']
 
     def step(a=img1, b=img2):
         preds = model([a, b], training=False)
         if world > 1:
-            pending.append(all_gather_batch_async(preds[-1].as_subclass(torch.Tensor), world * B))
+            last = preds[-1].as_subclass(torch.Tensor)
+            if gather_async[0]:
+                try:
+                    pending.append(all_gather_batch_async(last, world * B))
+                except (RuntimeError, TypeError, NotImplementedError) as e:   # backend without async collectives
+                    print(f'[bench] async all-gather unavailable ({e}); using the blocking gather', file=sys.stderr)
+                    gather_async[0] = False
+            if not gather_async[0]:
+                return all_gather_batch(last, world * B)
             if len(pending) > 1:
                 return pending.pop(0).wait()
             return None
@@ -214,7 +223,8 @@ def main():
                    'detail': f'all {ITERS} upsampled predictions produced per pair, Keras-default random weights, inputs '
                              'resident in HBM',
                    'pairs_per_gpu': B, 'global_batch': world * B, 'parallelism': f'dp{world}',
-                   'collective': 'all_gather(flow_predictions[-1]) over RCCL' if world > 1 else 'none'},
+                   'collective': ('all_gather(flow_predictions[-1]) over RCCL'
+                                  + (', in flight under the next step' if gather_async[0] else '')) if world > 1 else 'none'},
     }
 
     if rank == 0 and world == 1:
