@@ -150,11 +150,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)')
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # RAFT_BENCH_BACKEND=gloo: dry run of the N > 1 control flow on a box with fewer GPUs than ranks (ranks then share
+    # devices round-robin; gloo stages the device tensors through the host) -- never a measurement
+    backend = os.environ.get('RAFT_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import tf_raft_amd
     from tf_raft_amd import _dev, _ffi
@@ -223,7 +230,7 @@ def main():
                    'detail': f'all {ITERS} upsampled predictions produced per pair, Keras-default random weights, inputs '
                              'resident in HBM',
                    'pairs_per_gpu': B, 'global_batch': world * B, 'parallelism': f'dp{world}',
-                   'collective': ('all_gather(flow_predictions[-1]) over RCCL'
+                   'collective': ('all_gather(flow_predictions[-1]) over ' + ('RCCL' if backend == 'nccl' else backend + ' (DRY RUN of the control flow, not a measurement)')
                                   + (', in flight under the next step' if gather_async[0] else '')) if world > 1 else 'none'},
     }
 
