@@ -59,11 +59,12 @@ __global__ void __launch_bounds__(256 * KS, KS == 2 ? 1 : ((TNW == 1 && !SB && !
     constexpr int NA = (HP * QS + NTHR - 1) / NTHR;            // float4 items per thread per stage
     constexpr int A_BUF = HP * LDA + 4;                        // + one dummy 16-byte slot for padding items
     constexpr int BN = 32 * TNW;
-    // weight fragments are fetched PF taps ahead into a ring of NR: two taps (16 MFMAs) at TNW = 2; at TNW = 1 a tap is only
-    // four MFMAs per wave and two taps do not cover an L2 round trip when few waves share the SIMD (small batches), so
-    // the two-workgroup-per-CU variants, which have the registers, run RAFT_WINO_PF1 taps ahead and the others three
+    // weight fragments are fetched PF taps ahead into a ring of NR: two taps at TNW = 2 (16 MFMAs) and in the three-
+    // workgroups-per-CU variant (large grids: other waves cover the round trip, and a third tap costs it 4 spilled
+    // registers); three taps in the other TNW = 1 variants, where a tap is only four MFMAs per wave and two taps do not
+    // cover an L2 round trip when few waves share the SIMD (small batches)
     constexpr bool OCC3 = TNW == 1 && !SB && !PRE && CK == 1;  // the three-workgroups-per-CU launch bound above
-    constexpr int PF = TNW == 2 ? RAFT_WINO_PF2 : (OCC3 ? 3 : RAFT_WINO_PF1);
+    constexpr int PF = (TNW == 2 || OCC3) ? RAFT_WINO_PF2 : RAFT_WINO_PF1;
     constexpr int NR = PF < 4 ? 4 : 8;
     static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q,
                   "winograd kernel: linear / relu / residual / GRU gate epilogues");
