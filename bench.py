@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Benchmark of the RAFT forward-prediction hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-runs itself as N ranks under
+                                                            torch.distributed.run on 127.0.0.1, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -16,7 +17,9 @@ on 8 GPUs) unless --batch says otherwise.
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
   roofline            the dominant kernel (by accumulated time): achieved = the FLOPs the kernel EXECUTES on the MFMA
-                      pipe per launch / its HIP-event time, frac = achieved / 157.3 TF (<= 1 by construction).  A layer on
+                      pipe per launch / its HIP-event time net of the calibrated event bracket (the figure rocprofv3's kernel
+                      duration agrees with; achieved_between_events / frac_between_events = the raw interval, a strict
+                      upper bound on the kernel's duration), frac = achieved / 157.3 TF.  A layer on
                       a Winograd kernel executes fewer multiplies than the direct convolution it computes; the
                       direct-convolution figure is kept as algorithmic_tflops / frac_algorithmic (may exceed 1)
   roofline_corr_lookup the HBM-bound lookup kernel the north star singles out
@@ -50,7 +53,7 @@ STAGES = ['corr_lookup', 'convc1', 'convc2', 'convf1', 'convf2', 'conv', 'gru_zr
 
 # Layers that run on a Winograd kernel execute fewer multiplies than the convolution they compute: F(2x2, 3x3) 16 per
 # 36 (conv_wino.h), F(2, 5) 6 per 10 and F(4, 5) 8 per 20 (conv_wino1d.h).  roofline.achieved counts the FLOPs EXECUTED on
-# the MFMA pipe (direct FLOPs / this factor), so frac <= 1; the direct-convolution figure is kept as algorithmic_tflops.
+# the MFMA pipe (direct FLOPs / this factor); the direct-convolution figure is kept as algorithmic_tflops.
 WINOGRAD_ALGORITHMS = {2.25: 'Winograd F(2x2,3x3)', 10.0 / 6.0: 'Winograd F(2,5)', 2.5: 'Winograd F(4,5)'}
 
 
@@ -131,6 +134,88 @@ def pmc_traffic(kernel, B):
     return int(round(per_pair * B)), note
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU) through
+    torch.distributed.run, rendezvous on 127.0.0.1 at a free port.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def ranks_seen(dist, world, rank, device):
+    """Every rank contributes its id to an all-gather over the job's backend; the number of distinct ids that arrive
+    is what the line reports as `ranks_seen` (world size when the collective really spans all ranks)."""
+    import torch
+    mine = torch.tensor([rank], device=device, dtype=torch.int64)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return len({int(t.item()) for t in out})
+
+
+def dry_run_cpu(args, world, rank):
+    """RAFT_BENCH_DRY_RUN=cpu: the launcher / rendezvous / barrier / in-flight gather / max-over-ranks / rank-0 line
+    control flow of `--gpus N` with NO model and NO GPU (gloo, a zero tensor of the prediction's shape per step).
+    Exists so that tests/test_distributed_cpu.py can run `python bench.py --gpus 2` end to end in a CPU container;
+    the line says `dry_run` and its value means nothing."""
+    import torch
+    import torch.distributed as dist
+    from tf_raft_amd.parallel import all_gather_batch_async
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    B = args.batch or 2
+    pending = []
+
+    def step():
+        last = torch.full((B, 8, 8, 2), float(rank))
+        if world > 1:
+            pending.append(all_gather_batch_async(last, world * B))
+            if len(pending) > 1:
+                return pending.pop(0).wait()
+        return last
+
+    def fence():
+        while pending:
+            got = pending.pop(0).wait()
+            assert got.shape[0] == world * B and float(got[-1, 0, 0, 0]) == world - 1
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    seen = 1
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        seen = ranks_seen(dist, world, rank, torch.device('cpu'))
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'image-pairs/sec at 448x512 iters_pred=24', 'value': 0.0, 'unit': 'image-pairs/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'none',
+            'dry_run': 'control flow only: no model, no GPU (RAFT_BENCH_DRY_RUN=cpu)', 'ranks_seen': seen,
+            'config': {'workload': 'DRY RUN', 'pairs_per_gpu': B, 'global_batch': world * B, 'parallelism': f'dp{world}',
+                       'collective': 'all_gather over gloo (dry run)'}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -143,12 +228,17 @@ def main():
     ap.add_argument('--cpu-runs', type=int, default=2)
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on
+        # 127.0.0.1 (the container hostname may not resolve); rank 0's JSON line is this process's output
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU')
+    if os.environ.get('RAFT_BENCH_DRY_RUN') == 'cpu':
+        return dry_run_cpu(args, world, rank)
     import torch.distributed as dist
     # RAFT_BENCH_BACKEND=gloo: dry run of the N > 1 control flow on a box with fewer GPUs than ranks (ranks then share
     # devices round-robin; gloo stages the device tensors through the host) -- never a measurement
@@ -220,6 +310,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * B * args.steps / elapsed
+    seen = ranks_seen(dist, world, rank, device) if world > 1 else 1
 
     result = {
         'metric': 'image-pairs/sec at 448x512 iters_pred=24', 'value': round(value, 3), 'unit': 'image-pairs/s',
@@ -233,6 +324,22 @@ def main():
                    'collective': ('all_gather(flow_predictions[-1]) over ' + ('RCCL' if backend == 'nccl' else backend + ' (DRY RUN of the control flow, not a measurement)')
                                   + (', in flight under the next step' if gather_async[0] else '')) if world > 1 else 'none'},
     }
+
+    if world > 1:
+        result['ranks_seen'] = seen                      # distinct rank ids that arrived through the job's all-gather
+        result['backend'] = 'RCCL ' + '.'.join(str(v) for v in torch.cuda.nccl.version()) if backend == 'nccl' else backend
+        # ONE GPU at the same per-GPU shape, no collective: rank 0 alone, the other ranks wait at the closing barrier.
+        # The driver computes scaling efficiency from its own N = 1 run; this is the like-for-like figure beside it.
+        if rank == 0:
+            for _ in range(2):
+                model([img1, img2], training=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n1 = max(1, min(args.steps, 5))
+            for _ in range(n1):
+                model([img1, img2], training=False)
+            torch.cuda.synchronize()
+            result['one_gpu_same_shape_pairs_per_s'] = round(B * n1 / (time.perf_counter() - t0), 3)
 
     if rank == 0 and world == 1:
         # ---------------- informational: RAFT.predict_step (flow_predictions[-1] only: mask head + upsampling in the
@@ -350,7 +457,9 @@ def main():
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': tr,
                     'flops_per_launch': flops[dom] / ratio, 'ms_per_launch': stage_ms[dom],
                     'ms_per_launch_between_events': stage_ms_events[dom], 'traffic_source': note,
-                    'flops_counted': 'executed on the MFMA pipe'}
+                    'flops_counted': 'executed on the MFMA pipe',
+                    'achieved_between_events': round(flops[dom] / ratio / (stage_ms_events[dom] * 1e-3) / 1e12, 2),
+                    'frac_between_events': round(flops[dom] / ratio / (stage_ms_events[dom] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
             if ratio != 1.0:
                 roof['algorithm'] = WINOGRAD_ALGORITHMS[ratio]
                 roof['direct_conv_flops_per_launch'] = flops[dom]

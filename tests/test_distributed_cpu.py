@@ -150,3 +150,29 @@ def test_learning_rate_schedule_and_scalers():
     assert inv(30) == pytest.approx(1e-4 + 1e-4 * 0.5)                   # peak of the second cycle, scaled by 1/2
     with pytest.raises(ValueError):
         training.CyclicalLearningRate(1e-4, 2e-4, 10, scale_mode='epoch')
+
+
+def test_bench_gpus2_self_launches_without_torchrun():
+    """`python bench.py --gpus 2` typed WITHOUT a launcher (what a driver may do) must become two ranks on its own and
+    print rank 0's single JSON line.  RAFT_BENCH_DRY_RUN=cpu swaps the model for a zero tensor so that the launcher,
+    rendezvous on 127.0.0.1, in-flight gathers, closing barrier and max-over-ranks timing run in this CPU container."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['RAFT_BENCH_DRY_RUN'] = 'cpu'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['steps'] == 3 and line['warmup'] == 1
+    assert line['config']['global_batch'] == 2 * line['config']['pairs_per_gpu'] and 'dry_run' in line
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0', RAFT_BENCH_DRY_RUN='cpu')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode != 0 and 'WORLD_SIZE=3' in out.stderr
