@@ -439,3 +439,26 @@ def test_product_package_never_imports_the_oracle():
                     with open(os.path.join(dirpath, fn)) as f:
                         src = f.read()
                     assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(dirpath, fn)
+
+
+def test_a_stale_library_is_never_loaded_silently(monkeypatch):
+    """if refreshing the build fails while an older libraft_hip.so exists, loading it must be an error (or an
+    explicit opt-in) when it was built from other sources, and a warning when it is up to date."""
+    from tf_raft_amd import _ffi, build
+
+    def broken(**kw):
+        raise RuntimeError('simulated compile error')
+    monkeypatch.setattr(_ffi, '_LIB', None)
+    monkeypatch.setattr(build, 'build_library', broken)
+    monkeypatch.setattr(build, 'built_digest', lambda: 'digest-of-older-sources')
+    monkeypatch.delenv('RAFT_ALLOW_STALE_LIB', raising=False)
+    with pytest.raises(RuntimeError, match='built from different sources'):
+        _ffi.load_library()
+    monkeypatch.setenv('RAFT_ALLOW_STALE_LIB', '1')
+    with pytest.warns(RuntimeWarning, match='STALE'):
+        assert _ffi.load_library().raft_version() == _ffi.ABI_VERSION
+    monkeypatch.setattr(_ffi, '_LIB', None)
+    monkeypatch.delenv('RAFT_ALLOW_STALE_LIB')
+    monkeypatch.setattr(build, 'built_digest', build.source_digest)
+    with pytest.warns(RuntimeWarning, match='up-to-date'):
+        _ffi.load_library()

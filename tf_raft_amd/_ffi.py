@@ -156,6 +156,16 @@ def load_library():
                 raise RuntimeError(
                     f'libraft_hip.so is missing at {path} and could not be built ({exc}); '
                     'the RAFT device path has no CPU fallback') from exc
+            # A library exists but the refresh failed (compile error, no hipcc, read-only tree).  It may only be used
+            # if it was built from exactly these sources; anything else would run old kernels under new tests.
+            stale = _build.built_digest() != _build.source_digest()
+            if stale and os.environ.get('RAFT_ALLOW_STALE_LIB') != '1':
+                raise RuntimeError(
+                    f'{path} was built from different sources than the ones on disk and rebuilding failed: {exc}.  '
+                    'Fix the build, or set RAFT_ALLOW_STALE_LIB=1 to load the old library knowingly') from exc
+            import warnings
+            warnings.warn(f'libraft_hip.so could not be refreshed ({exc}); loading the existing '
+                          f'{"STALE " if stale else "up-to-date "}library at {path}', RuntimeWarning, stacklevel=2)
         try:
             lib = C.CDLL(path)
         except OSError as exc:

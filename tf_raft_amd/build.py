@@ -22,6 +22,9 @@ SOURCES = ['corr.hip', 'upsample.hip', 'conv.hip', 'conv_halo_11.hip', 'conv_hal
 HEADERS = ['common.h', 'conv_mfma.h', 'conv_halo.h', 'conv_wino.h', 'conv_wino1d.h', 'lookup_common.h', os.path.join('..', '..', 'include', 'raft_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on',
          '-Wall', '-Wno-unused-function']
+# diagnostic builds (e.g. RAFT_BUILD_DEFINES=-DRAFT_FUSED_PROBE for tools/fused_probe.py): part of the digest, so the
+# next ordinary load rebuilds the product library
+FLAGS += os.environ.get('RAFT_BUILD_DEFINES', '').split()
 
 
 def _hipcc():
@@ -40,6 +43,27 @@ def _digest(paths):
     return h.hexdigest()
 
 
+def _inputs():
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    return srcs, hdrs
+
+
+def source_digest() -> str:
+    """Digest of the sources + flags as they are on disk now."""
+    srcs, hdrs = _inputs()
+    return _digest(srcs + hdrs)
+
+
+def built_digest():
+    """Digest the existing libraft_hip.so was built from (None: no library or no stamp)."""
+    stamp = os.path.join(LIBDIR, 'build.sha256')
+    if not (os.path.exists(LIBPATH) and os.path.exists(stamp)):
+        return None
+    with open(stamp) as f:
+        return f.read().strip()
+
+
 def build_library(force: bool = False, verbose: bool = True) -> str:
     """Build (or reuse) the library.  Safe against concurrent callers -- e.g. the 8 ranks of a multi-GPU launch on a box
     without a prebuilt .so: an inter-process file lock serialises them, the first builds, the others reuse; the shared
@@ -55,8 +79,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
 
 
 def _build_locked(force: bool, verbose: bool) -> str:
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    srcs, hdrs = _inputs()
     stamp = os.path.join(LIBDIR, 'build.sha256')
     digest = _digest(srcs + hdrs)
     if not force and os.path.exists(LIBPATH) and os.path.exists(stamp):

@@ -683,13 +683,21 @@ extern "C" int raft_lookup_convc1_f32(const float *pyr, const int64_t *level_off
     a.npad = npad;
     a.nvalid = nvalid;
     const int grid = raft_ceil_div(a.lk.nq, FL_QB * FL_ROUNDS);
-    const int abl = raft_opt(RAFT_OPT_LOOKUP_FUSED, 1);   // 1 = the kernel; 11 / 12 = diagnostic builds (tools/fused_probe.py)
-    if (abl == 11)
+#ifdef RAFT_FUSED_PROBE
+    // diagnostic builds only (tools/fused_probe.py compiles its own copy with -DRAFT_FUSED_PROBE): RAFT_LOOKUP_FUSED
+    // 11 / 12 select the phase-ablated kernels, which do NOT compute the function.  The library never contains them:
+    // every setting of every switch of the shipped .so computes the same result (include/raft_hip.h).
+    const int abl = raft_opt(RAFT_OPT_LOOKUP_FUSED, 1);
+    if (abl == 11) {
         lookup_convc1_kernel<4, 1><<<grid, FL_THREADS, 0, (hipStream_t)stream>>>(a);
-    else if (abl == 12)
+        return raft_launch_status();
+    }
+    if (abl == 12) {
         lookup_convc1_kernel<4, 2><<<grid, FL_THREADS, 0, (hipStream_t)stream>>>(a);
-    else
-        lookup_convc1_kernel<4, 0><<<grid, FL_THREADS, 0, (hipStream_t)stream>>>(a);
+        return raft_launch_status();
+    }
+#endif
+    lookup_convc1_kernel<4, 0><<<grid, FL_THREADS, 0, (hipStream_t)stream>>>(a);
     return raft_launch_status();
 }
 

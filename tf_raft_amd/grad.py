@@ -228,9 +228,9 @@ def update_block_forward(weights, net, inp, corr, flow, prefix='update_block', v
     h = net
     for g in cfg['gru']:                                                           # update.py:51-67 / 26-35
         kzr = _cached(w[f'{p}/gru/convz{g}/kernel'], 'kzr', lambda: np.concatenate(
-            [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3))
+            [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3), also=w[f'{p}/gru/convr{g}/kernel'])
         bzr = _cached(w[f'{p}/gru/convz{g}/bias'], 'bzr', lambda: np.concatenate(
-            [w[f'{p}/gru/convz{g}/bias'], w[f'{p}/gru/convr{g}/bias']]))
+            [w[f'{p}/gru/convz{g}/bias'], w[f'{p}/gru/convr{g}/bias']]), also=w[f'{p}/gru/convr{g}/bias'])
         hx = torch.cat([h, x], dim=-1).contiguous()
         a_zr = _conv_fwd(hx, kzr, bzr)
         z, r, rh = (torch.empty_like(h) for _ in range(3))
@@ -303,7 +303,7 @@ def update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update
         check(lib.raft_gru_gate_r_backward_f32(_dev.ptr(d_rh), _dev.ptr(r), _dev.ptr(h_in), n_h, _dev.ptr(dr_pre), _dev.ptr(dh_in),
                                                _dev.stream_ptr()), 'gate_r_backward')
         kzr = _cached(w[f'{p}/gru/convz{g}/kernel'], 'kzr', lambda: np.concatenate(
-            [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3))
+            [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3), also=w[f'{p}/gru/convr{g}/kernel'])
         d_zr = torch.cat([dz_pre, dr_pre], dim=-1).contiguous()
         d_hx, dk, db = conv_b(None, s[f'hx{g}'], d_zr, kernel=kzr)
         grads[f'{p}/gru/convz{g}/kernel'], grads[f'{p}/gru/convr{g}/kernel'] = dk[..., :hd].contiguous(), dk[..., hd:].contiguous()

@@ -1,5 +1,11 @@
-"""Time raft_lookup_convc1_f32 and its two phases alone (GPU box).  python tools/fused_probe.py [B]"""
+"""Time raft_lookup_convc1_f32 and its two phases alone (GPU box).
+
+    RAFT_BUILD_DEFINES=-DRAFT_FUSED_PROBE python tools/fused_probe.py [B]
+
+The phase-ablated kernels (RAFT_LOOKUP_FUSED = 11 / 12) exist only in a library built with -DRAFT_FUSED_PROBE; the
+product library does not contain them (the next ordinary import rebuilds it: the define is part of the build digest)."""
 import os
+assert '-DRAFT_FUSED_PROBE' in os.environ.get('RAFT_BUILD_DEFINES', ''), __doc__
 import sys
 
 import numpy as np
