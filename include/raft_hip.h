@@ -28,6 +28,8 @@
  *                       (0..5 legacy (tap, chunk)-stepped tiles; 100 + 10*TH + TN halo tiles, TH in {4,7,8})
  *   RAFT_CONV_DEEP      0/1  deep weight prefetch of the single-column-block halo tiles          (default 1)
  *   RAFT_CONV_WINO      bit mask {1 convc2, 2 convf2, 4 conv, 8 fh1_mask0}: layers on the F(2x2,3x3) kernel (13)
+ *   RAFT_CONV_WINO4     the same mask for the F(4x4,3x3) kernel, preferred where its bit is set and the 6x6-tap weights
+ *                       were supplied                                                             (default 8: fh1_mask0)
  *   RAFT_SMALL_WINO     bit mask {1 conv, 2 gru_zr, 4 gru_q, 8 fh1} of the SmallUpdateBlock      (default 15)
  *   RAFT_GRU_WINO       bit mask {1 zr1, 2 q1, 4 zr2, 8 q2}: SepConvGRU layers on F(2,5)         (default 15)
  *   RAFT_GRU_WINO4      the same mask for F(4,5), preferred where both bits are set              (default 15)
@@ -56,7 +58,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 209          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 210          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -188,6 +190,14 @@ int raft_conv2d_winograd_f32(const float *a0, int lda0, int c0, const float *a1,
                              const float *wp, const float *bias, int B, int H, int W, int npad,
                              int nvalid, int act, float scale, float *out, int ldo, void *stream);
 
+/* The same by Winograd F(4x4, 3x3) (36 multiplies per 16 outputs: 4x fewer than the direct kernel, 1.78x fewer than
+ * F(2x2, 3x3); fp32, points {0, +-5/8, +-3/2, inf}; deviation from the float64 convolution ~3x that of F(2x2, 3x3)).
+ * `wp` = the transformed kernel in the consumption order of the kernel, (Cin/16, 72, 4, npad, 2) -- packing.py
+ * pack_conv_winograd4; c0, c1 multiples of 16, npad a multiple of 64. */
+int raft_conv2d_winograd4_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                              const float *wp, const float *bias, int B, int H, int W, int npad,
+                              int nvalid, int act, float scale, float *out, int ldo, void *stream);
+
 /* 1x5 (kh = 1, kw = 5) or 5x1 convolution by 1-D Winograd F(2, 5) (6 multiplies per output pair instead of 10;
  * fp32, points {0, +-1, +-1/2, inf}).  `wp` = the transformed kernel packed with 6 taps; c0, c1 multiples of 16. */
 int raft_conv1d_winograd_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
@@ -247,6 +257,9 @@ typedef struct raft_basic_update_weights {
     raft_conv_weights convc1_f;
     /* optional: 1-D Winograd F(4, 5) transformed copies of gru_ctx1 / gru_ctx2 (8-tap kernels, with the biases) */
     raft_conv_weights gru_ctx1_w4, gru_ctx2_w4;
+    /* optional: Winograd F(4x4, 3x3) transformed copies of convc2 / conv / fh1_mask0 and of flow_head.conv1 alone
+     * (packing.py pack_conv_winograd4); preferred over the F(2x2, 3x3) copies where RAFT_CONV_WINO4 has the layer's bit */
+    raft_conv_weights convc2_w44, conv_w44, fh1_mask0_w44, fh1_w44;
 } raft_basic_update_weights;
 
 /* Device state of the recurrent loop (all caller-owned, (B*h*w) pixels, NHWC):

@@ -393,6 +393,77 @@ def test_conv2d_winograd_matches_oracle(rng, shape, variant, raft_opt):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize('shape', [(2, 9, 13), (1, 8, 64), (1, 5, 70), (2, 16, 128), (1, 56, 64)])   # ragged, exact, 2 x-tiles + tail, big
+def test_conv2d_winograd4_matches_oracle(rng, shape):
+    """Winograd F(4x4, 3x3) kernel (conv_wino4.h) against the float64 direct convolution; two sources (the first one
+    padded 40 -> 48 channels), N tail 150 -> 192.  Its fp32 deviation is ~3x that of the F(2x2, 3x3) kernel (reported
+    next to it and to the direct kernel): bound 6e-5 on outputs of magnitude ~10 where the other kernels have 2e-5."""
+    from oracle import tf_ops
+    from tf_raft_amd import _dev, packing
+    from tf_raft_amd._ffi import check
+    B, H, W = shape
+    c_a, c_b, cout = 40, 64, 150
+    xa = rng.normal(size=(B, H, W, c_a)).astype(np.float32)
+    xb = rng.normal(size=(B, H, W, c_b)).astype(np.float32)
+    kernel = (rng.normal(size=(3, 3, c_a + c_b, cout)) * 0.1).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    srcs = []
+    for arr, cpad in ((xa, 48), (xb, 64)):
+        buf = np.zeros((B, H, W, cpad), np.float32)
+        buf[..., :arr.shape[-1]] = arr
+        srcs.append(_dev.to_device(buf))
+    wp, b, npad = packing.pack_conv_winograd4(kernel, bias, [(c_a, 48), (c_b, 64)])
+    assert wp.shape == (7, 72, 4, npad, 2) and npad == 192
+    wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
+    out = torch.full((B, H, W, cout), float('nan'), device=srcs[0].device)
+    check(_dev.lib().raft_conv2d_winograd4_f32(_dev.ptr(srcs[0]), 48, 48, _dev.ptr(srcs[1]), 64, 64, _dev.ptr(wp_d),
+                                               _dev.ptr(b_d), B, H, W, npad, cout, 1, 0.5, _dev.ptr(out), cout,
+                                               _dev.stream_ptr()), 'conv2d_winograd4')
+    torch.cuda.synchronize()
+    got = _np(out)
+    x = torch.cat([_t(xa), _t(xb)], dim=-1)
+    want = 0.5 * torch.relu(tf_ops.conv2d(x.double(), _t(kernel).double(), _t(bias).double())).numpy()
+    direct = _conv_device([(xa, 64), (xb, 64)], kernel, bias, act=1, scale=0.5)
+    err, err_direct = float(np.abs(got - want).max()), float(np.abs(direct - want).max())
+    report(f'conv2d winograd F(4x4,3x3) {shape}', max_abs_vs_f64=err, direct_vs_f64=err_direct,
+           rms_vs_f64=float(np.sqrt(((got - want) ** 2).mean())), rms_direct=float(np.sqrt(((direct - want) ** 2).mean())))
+    assert not np.isnan(got).any()
+    if err >= 6e-5:   # locate a structural fault from one run: worst pixel / channel and the error pattern over tile positions
+        e = np.abs(got - want)
+        bb, yy, xx, nn = np.unravel_index(int(e.argmax()), e.shape)
+        pos = np.array([[e[:, i::4, j::4].max() for j in range(4)] for i in range(4)])
+        print(f'[wino4] worst at b {bb} y {yy} x {xx} n {nn}: got {got[bb, yy, xx, nn]} want {want[bb, yy, xx, nn]}')
+        print('[wino4] max error by position inside the 4x4 tile:\n', pos)
+        print('[wino4] max error by channel block of 16:', [float(e[..., k:k + 16].max()) for k in range(0, cout, 16)])
+        print('[wino4] max error by row:', [float(e[:, y].max()) for y in range(H)])
+        print('[wino4] max error by column (first 72):', [round(float(e[:, :, x].max()), 5) for x in range(min(W, 72))])
+    assert err < 6e-5
+
+
+def test_conv2d_winograd4_linear_residual_and_rejections(rng):
+    """The linear epilogue with a scale, one source, channel counts that are exact multiples; argument rejections."""
+    from oracle import tf_ops
+    from tf_raft_amd import _dev, packing
+    from tf_raft_amd._ffi import check
+    B, H, W, cin, cout = 1, 12, 20, 32, 64
+    x = rng.normal(size=(B, H, W, cin)).astype(np.float32)
+    kernel = (rng.normal(size=(3, 3, cin, cout)) * 0.1).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    wp, b, npad = packing.pack_conv_winograd4(kernel, bias)
+    xd, wp_d, b_d = _dev.to_device(x), _dev.to_device(wp), _dev.to_device(b)
+    out = torch.full((B, H, W, cout), float('nan'), device=xd.device)
+    check(_dev.lib().raft_conv2d_winograd4_f32(_dev.ptr(xd), cin, cin, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, npad,
+                                               cout, 0, 2.0, _dev.ptr(out), cout, _dev.stream_ptr()), 'conv2d_winograd4')
+    torch.cuda.synchronize()
+    want = 2.0 * tf_ops.conv2d(_t(x).double(), _t(kernel).double(), _t(bias).double()).numpy()
+    err = float(np.abs(_np(out) - want).max())
+    report('conv2d winograd F(4x4,3x3) linear', max_abs_vs_f64=err)
+    assert err < 6e-5
+    rc = _dev.lib().raft_conv2d_winograd4_f32(_dev.ptr(xd), cin, 24, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, npad,
+                                              cout, 0, 1.0, _dev.ptr(out), cout, _dev.stream_ptr())
+    assert rc < 0                                                    # 24 channels: not a multiple of 16
+
+
 @pytest.mark.parametrize('tnw', ['1', '2', '1-ck2', '2-ck2', '2-ck2-tm1', '1-tm1', '2-tm2'])   # TNW, CK, TM variants
 @pytest.mark.parametrize('ksize', [(1, 5), (5, 1)])
 @pytest.mark.parametrize('shape', [(2, 9, 13), (1, 8, 64), (1, 21, 35)])

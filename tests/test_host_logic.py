@@ -462,3 +462,70 @@ def test_a_stale_library_is_never_loaded_silently(monkeypatch):
     monkeypatch.setattr(build, 'built_digest', build.source_digest)
     with pytest.warns(RuntimeWarning, match='up-to-date'):
         _ffi.load_library()
+
+
+def _wino4_emulate(x, wp, bias, cout):
+    """What conv_wino4_kernel computes, restated in NumPy from the PACKED weight stream: per 16-channel chunk and slot q
+    the tap (row, column, half) of packing.wino4_tap_of_slot, V = B^T d B by the kernel's two stages (fp32), products
+    accumulated per tap in fp32, A^T . A at the end.  x: (H, W, Cpad) with H, W multiples of 4."""
+    H, W, cpad = x.shape
+    nch, npad = wp.shape[0], wp.shape[3]
+    xp = np.zeros((H + 2, W + 2, cpad), np.float32)
+    xp[1:-1, 1:-1] = x
+    out = np.zeros((H, W, cout), np.float32)
+    for ty0 in range(0, H, 4):
+        for tx0 in range(0, W, 4):
+            d = xp[ty0:ty0 + 6, tx0:tx0 + 6]                                   # 6 x 6 x C patch
+            w_rows = np.stack(packing.wino4_transform_6([d[r] for r in range(6)]))           # stage 1: over patch rows
+            v = np.stack(packing.wino4_transform_6([w_rows[:, j] for j in range(6)]), axis=1)  # stage 2: [ty][tx][c]
+            acc = np.zeros((6, 6, npad), np.float32)
+            for c in range(nch):
+                for q in range(72):
+                    ty, tx, h = packing.wino4_tap_of_slot(q)
+                    for g in range(4):
+                        for e in range(2):
+                            ch = 16 * c + 4 * g + 2 * h + e
+                            acc[ty, tx] += v[ty, tx, ch] * wp[c, q, g, :, e]
+            t = np.stack(packing.wino4_output_4([acc[i] for i in range(6)]))                 # over tap rows: [i][tx][n]
+            y = np.stack(packing.wino4_output_4([t[:, j] for j in range(6)]), axis=1)        # [i][jx][n]
+            out[ty0:ty0 + 4, tx0:tx0 + 4] = y[:, :, :cout] + bias[:cout]
+    return out
+
+
+def test_winograd4_transforms_and_packed_stream_reproduce_the_convolution(rng):
+    """F(4x4, 3x3) with the points {0, +-5/8, +-3/2, inf}: the Cook-Toom matrices are exact, the pair-structured
+    formulas the HIP kernel hard-codes (csrc/conv_wino4.h) equal B^T / A^T, and the packed weight stream walked in the
+    kernel's slot order reproduces the 3x3 'same' convolution (two sources, padded channels)."""
+    AT, G, BT = packing.cook_toom((0, packing.WINO4_A, -packing.WINO4_A, packing.WINO4_B, -packing.WINO4_B), 4, 3)
+    assert AT.shape == (4, 6) and G.shape == (6, 3) and BT.shape == (6, 6)
+    d = rng.normal(size=(6, 7))
+    np.testing.assert_allclose(np.stack(packing.wino4_transform_6(list(d))), BT @ d, atol=1e-12)
+    np.testing.assert_allclose(np.stack(packing.wino4_output_4(list(d))), AT @ d, atol=1e-12)
+    # 1-D: y[i] = sum_k d[i + k] g[k]
+    g = rng.normal(size=3)
+    np.testing.assert_allclose(AT @ ((G @ g) * (BT @ d[:, 0])), [d[i:i + 3, 0] @ g for i in range(4)], atol=1e-12)
+    # every B^T / A^T coefficient is exact in fp32 (dyadic points)
+    assert np.all(BT.astype(np.float32) == BT) and np.all(AT.astype(np.float32) == AT)
+    # slots: each (tap, half) exactly once
+    slots = [packing.wino4_tap_of_slot(q) for q in range(72)]
+    assert sorted(slots) == sorted((ty, tx, h) for ty in range(6) for tx in range(6) for h in range(2))
+    # packed stream vs the convolution
+    c_a, c_b, cout = 20, 16, 10
+    kernel = (rng.normal(size=(3, 3, c_a + c_b, cout)) * 0.2).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    wp, b, npad = packing.pack_conv_winograd4(kernel, bias, [(c_a, 32), (c_b, 16)])
+    assert wp.shape == (3, 72, 4, 64, 2) and npad == 64 and wp.dtype == np.float32
+    xa, xb = rng.normal(size=(8, 12, c_a)).astype(np.float32), rng.normal(size=(8, 12, c_b)).astype(np.float32)
+    x = np.zeros((8, 12, 48), np.float32)
+    x[..., :c_a], x[..., 32:] = xa, xb
+    got = _wino4_emulate(x, wp, b, cout)
+    xcat = np.concatenate([xa, xb], -1).astype(np.float64)
+    xpad = np.pad(xcat, ((1, 1), (1, 1), (0, 0)))
+    want = np.zeros((8, 12, cout))
+    for u in range(3):
+        for v in range(3):
+            want += np.einsum('hwc,co->hwo', xpad[u:u + 8, v:v + 12], kernel[u, v].astype(np.float64))
+    want += bias
+    assert np.abs(got - want).max() < 2e-5, np.abs(got - want).max()
+    with pytest.raises(ValueError):
+        packing.pack_conv_winograd4(kernel, bias, [(c_a, 24), (c_b, 16)])

@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 209     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 210     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -29,7 +29,8 @@ class BasicUpdateWeights(C.Structure):
         'fh1_mask0', 'fh2', 'mask2', 'gru_ctx1', 'gru_ctx2',
         'convc2_w', 'convf2_w', 'conv_w', 'fh1_mask0_w',
         'gru_zr1_w', 'gru_q1_w', 'gru_zr2_w', 'gru_q2_w', 'fh1_w',
-        'gru_zr1_w4', 'gru_q1_w4', 'gru_zr2_w4', 'gru_q2_w4', 'convc1_f', 'gru_ctx1_w4', 'gru_ctx2_w4')]
+        'gru_zr1_w4', 'gru_q1_w4', 'gru_zr2_w4', 'gru_q2_w4', 'convc1_f', 'gru_ctx1_w4', 'gru_ctx2_w4',
+        'convc2_w44', 'conv_w44', 'fh1_mask0_w44', 'fh1_w44')]
 
 
 class SmallUpdateWeights(C.Structure):
@@ -107,6 +108,7 @@ _SIGNATURES = {
     'raft_conv2d_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I,
                              C.c_float, _P, _I, _P]),
     'raft_conv2d_winograd_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),
+    'raft_conv2d_winograd4_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),
     'raft_conv1d_winograd_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),
     'raft_conv1d_winograd4_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),
     'raft_update_workspace_floats': (C.c_int64, [_I, _I, _I]),

@@ -7,6 +7,7 @@
 #include "conv_halo.h"
 #include "conv_wino.h"
 #include "conv_wino1d.h"
+#include "conv_wino4.h"
 
 // ------------------------------------------------------------------------------------------------
 // tile selection + dispatch of the implicit-GEMM kernel
@@ -173,6 +174,25 @@ extern "C" int raft_conv2d_winograd_f32(const float *a0, int lda0, int c0, const
     return raft_launch_conv_wino(a, act == RAFT_ACT_RELU ? EPI_RELU : EPI_LINEAR, (hipStream_t)stream);
 }
 
+extern "C" int raft_conv2d_winograd4_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                                         const float *wp, const float *bias, int B, int H, int W, int npad, int nvalid,
+                                         int act, float scale, float *out, int ldo, void *stream) {
+    RAFT_REQUIRE_PTR(a0);
+    RAFT_REQUIRE_PTR(wp);
+    RAFT_REQUIRE_PTR(bias);
+    RAFT_REQUIRE_PTR(out);
+    RAFT_REQUIRE(c1 == 0 || a1 != nullptr, RAFT_E_NULL);
+    RAFT_REQUIRE(B > 0 && H > 0 && W > 0 && nvalid > 0 && nvalid <= npad && ldo >= nvalid, RAFT_E_SHAPE);
+    RAFT_REQUIRE(lda0 >= c0 && (c1 == 0 || lda1 >= c1), RAFT_E_SHAPE);
+    RAFT_REQUIRE(act == RAFT_ACT_NONE || act == RAFT_ACT_RELU, RAFT_E_UNSUPPORTED);
+    ConvArgs a = {};
+    a.a0 = a0; a.a1 = a1; a.lda0 = lda0; a.lda1 = lda1; a.c0 = c0; a.c1 = c1;
+    a.wp = wp; a.bias = bias; a.B = B; a.H = H; a.W = W;
+    a.npad = npad; a.nvalid = nvalid; a.hid = 0; a.scale = scale;
+    a.o0 = out; a.ldo0 = ldo;
+    return raft_launch_conv_wino4(a, act == RAFT_ACT_RELU ? EPI_RELU : EPI_LINEAR, (hipStream_t)stream);
+}
+
 static int conv1d_winograd(int mo, const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
                            const float *wp, const float *bias, int B, int H, int W, int kh, int kw,
                            int npad, int nvalid, int act, float scale, float *out, int ldo, void *stream) {
@@ -241,9 +261,17 @@ static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weig
 // B = 4).  Read per call so that tests can switch it.
 constexpr int RAFT_WINO_DEFAULT = 13;
 constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr, 4: gru_q, 8: fh1}, switch RAFT_SMALL_WINO
+constexpr int RAFT_WINO4_DEFAULT = 8;          // F(4x4, 3x3): {1: convc2, 4: conv, 8: fh1_mask0 / fh1}, switch RAFT_CONV_WINO4
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
-                          hipStream_t s, bool small = false) {
+                          hipStream_t s, bool small = false, const raft_conv_weights *wino44 = nullptr) {
     const int mask = small ? raft_opt(RAFT_OPT_SMALL_WINO, RAFT_SMALL_WINO_DEFAULT) : raft_opt(RAFT_OPT_CONV_WINO, RAFT_WINO_DEFAULT);
+    if (wino44 != nullptr && wino44->wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, RAFT_WINO4_DEFAULT) & bit) &&
+        (epi == EPI_LINEAR || epi == EPI_RELU || epi == EPI_RES)) {
+        a.wp = wino44->wp;
+        a.bias = wino44->bias;
+        a.npad = wino44->npad;
+        return raft_launch_conv_wino4(a, epi, s);
+    }
     if ((mask & bit) && wino.wp != nullptr) {
         a.wp = wino.wp;
         a.bias = wino.bias;
@@ -652,7 +680,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     {   // cor = relu(convc2(cor))             3x3, 256 -> 192   -> corflo[:, 0:192]
         ConvArgs a = conv_args(wts->convc2, cor1, 256, 256, nullptr, 0, 0, B, h, w, 192, corflo, 256);
-        RAFT_TRY(launch_conv3x3(wts->convc2, wts->convc2_w, 1, a, EPI_RELU, s));
+        RAFT_TRY(launch_conv3x3(wts->convc2, wts->convc2_w, 1, a, EPI_RELU, s, false, &wts->convc2_w44));
         RAFT_MARK();
     }
     if (ov) RAFT_HIP(hipStreamWaitEvent(sf, ov->e_fh, 0));   // flow of the previous iteration is final
@@ -672,7 +700,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     {   // out = relu(conv(cat[cor, flo]))     3x3, 256 -> 126   -> x[:, 128:254]; x[:, 254:256] = flow (kept by flowhead2)
         ConvArgs a = conv_args(wts->conv, corflo, 256, 256, nullptr, 0, 0, B, h, w, 126, st->x + 128, XDIM);
-        RAFT_TRY(launch_conv3x3(wts->conv, wts->conv_w, 4, a, EPI_RELU, s));
+        RAFT_TRY(launch_conv3x3(wts->conv, wts->conv_w, 4, a, EPI_RELU, s, false, &wts->conv_w44));
         RAFT_MARK();
     }
     // ---- SepConvGRU (update.py:51-67): hx = [h | x]; [r*h | x]
@@ -704,11 +732,12 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     if (ov && ov->have_up) RAFT_HIP(hipStreamWaitEvent(s, ov->e_up, 0));   // mask2 / upsample of the previous iteration
     if (with_mask) {   // relu(flow_head.conv1(net)) | relu(mask.0(net))   3x3, 128 -> 256 + 256
         ConvArgs a = conv_args(wts->fh1_mask0, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 512, fm, 512);
-        RAFT_TRY(launch_conv3x3(wts->fh1_mask0, wts->fh1_mask0_w, 8, a, EPI_RELU, s));
+        RAFT_TRY(launch_conv3x3(wts->fh1_mask0, wts->fh1_mask0_w, 8, a, EPI_RELU, s, false, &wts->fh1_mask0_w44));
         RAFT_MARK();
     } else {           // relu(flow_head.conv1(net)) only            3x3, 128 -> 256        -> fm[:, 0:256]
-        ConvArgs a = conv_args(wts->fh1_w, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 256, fm, 512);
-        RAFT_TRY(raft_launch_conv_wino(a, EPI_RELU, s));
+        const bool w44 = wts->fh1_w44.wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, RAFT_WINO4_DEFAULT) & 8);
+        ConvArgs a = conv_args(w44 ? wts->fh1_w44 : wts->fh1_w, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 256, fm, 512);
+        RAFT_TRY(w44 ? raft_launch_conv_wino4(a, EPI_RELU, s) : raft_launch_conv_wino(a, EPI_RELU, s));
     }
     if (ov) {
         RAFT_HIP(hipEventRecord(ov->e_fm, s));

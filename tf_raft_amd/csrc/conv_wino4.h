@@ -1,0 +1,418 @@
+// Winograd F(4x4, 3x3) stride-1 'same' convolution on fp32 MFMA (v_mfma_f32_16x16x4_f32) for gfx950.
+//
+// Y = A^T [ (G g G^T) (.) (B^T d B) ] A with the interpolation points {0, +-5/8, +-3/2, inf} (tap order [0, +a, -a, +b, -b,
+// inf]; matrices and the reason for these points: tf_raft_amd/packing.py, tools/study/wino_error.py).  A 4x4 output tile
+// costs 36 multiplies per (input channel, output channel) instead of 144: 4x fewer MACs than the direct kernel and 1.78x
+// fewer than F(2x2, 3x3) (conv_wino.h).  fp32 throughout; U = G g G^T is evaluated on the host in float64 and rounded once.
+// Measured deviation from the float64 convolution: ~3x that of F(2x2, 3x3), ~5x that of the direct fp32 kernel
+// (tests/test_gpu_kernels.py reports all three); the F(2x2) and direct kernels stay selectable (RAFT_CONV_WINO4 = 0).
+//
+// Work decomposition (why it differs from conv_wino.h): 36 independent tap-GEMMs keep 36 accumulator tiles per (row block,
+// column block) alive until the output transform -- 144 registers per 16 tiles x 16 channels.  Two column blocks per wave
+// (so that one transformed input feeds two MFMAs) are 288 accumulator registers: ONE wave per SIMD with the 512-register
+// budget, accumulators in AGPRs.  Nothing hides a stall for a lone wave, so the K loop is a hand-placed software pipeline:
+//
+//   * MFMA row = one 4x4 output tile, row block = 16 tiles along x (4 rows x 64 columns).  Workgroup = 4 waves = 2 row
+//     blocks (8 x 64 pixels) x 2 pairs of column blocks (64 channels); wave w: row block w & 1, channel pair w >> 1.
+//   * K is walked in 16-channel chunks; the 10 x 66 halo tile of a chunk sits in LDS (double-buffered, ONE barrier per
+//     chunk).  Pixel x of a halo row is at x * 16 + (x >> 2) * 4 floats and its 16 channels are stored as [half][quad][2]:
+//     lane (tile LR, k-quad G) reads channels (4G + 2h, 4G + 2h + 1) of its patch as ds_read_b64 at lane stride 68 LR +
+//     2 G floats -- conflict-free (tools/bank_check.py wino4).  A chunk is processed as two halves h (k-steps 2h, 2h + 1 of
+//     every tap) so that the transform works on 2 channels per lane: W and V are 12 registers a row instead of 24.
+//   * A half is three PHASES of two tap rows each -- (+a, -a), (+b, -b), (0, inf): rows of a pair share their even / odd
+//     parts.  Stage 1 (B^T over the patch rows -> W[2][6]) of phase k + 1 is spread over the 12 tap slots of phase k (LDS
+//     reads in even slots, arithmetic in odd slots); stage 2 (W -> V, one tap ahead) and the weight fragments (PF slots
+//     ahead, straight from L2 as b64 per lane and column block) ride in the same slots; a slot ends in its 4 MFMAs
+//     (2 k-steps x 2 column blocks).  The next chunk's halo tile is fetched item by item in slots 4..14 and written to the
+//     other LDS buffer in slots 10..20; the chunk's barrier sits in front of its last phase, whose stage-1 reads already
+//     belong to the next chunk.
+//   * epilogue: A^T . A over the 36 accumulators of a column block (lane-local), bias, relu / residual, stores with one lane
+//     base per tensor + wave-uniform element offsets (as conv_wino.h).
+#pragma once
+#include "conv_mfma.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#include <type_traits>
+#include <utility>
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  The accumulator
+// of a tap is selected in the FRONT END (if constexpr over named variables): one array of 72 tiles is never promoted to
+// registers by hipcc (too many uses of one alloca), and a switch over 72 cases x 288 call sites is not unrolled.
+template <class F, int... I>
+__device__ __forceinline__ void w4_static_for_impl(F &f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void w4_static_for(F &&f) {
+    w4_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+#define W4_TILES(X)                                                                                                      \
+    X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21)   \
+    X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41)    \
+    X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61)    \
+    X(62) X(63) X(64) X(65) X(66) X(67) X(68) X(69) X(70) X(71)
+
+#ifndef RAFT_WINO4_PF
+#define RAFT_WINO4_PF 4      // weight fragments are fetched this many tap slots (4 MFMAs each) ahead
+#endif
+#ifndef RAFT_WINO4_ATILES
+#define RAFT_WINO4_ATILES 62  // accumulator tiles (of 72) kept in AGPRs
+#endif
+#ifndef RAFT_WINO4_ABL
+#define RAFT_WINO4_ABL 0     // tools/ablate: 1 no weight loads in the loop, 2 no stage 1, 4 no halo staging, 8 no stores
+#endif
+
+namespace wino4 {
+constexpr float PA = 0.625f, PB = 1.5f;
+constexpr float A2 = PA * PA, B2 = PB * PB, SS = A2 + B2, PP = A2 * B2, A3 = A2 * PA, B3 = B2 * PB;
+constexpr int TW = 64, TH = 8, HH = TH + 2, HWP = TW + 2, HP = HH * HWP;   // 10 x 66 halo pixels
+constexpr int RS = 1124;                       // floats per halo row: 66 * 16 + 17 * 4
+constexpr int A_BUF = HH * RS + 16;            // + one dummy pixel for the padding items of the staging loop
+constexpr int NTHR = 256;
+constexpr int NA = (HP * 4 + NTHR - 1) / NTHR; // 16-byte items per thread per chunk (11)
+constexpr int PF = RAFT_WINO4_PF, NR = 8;
+constexpr int W4_ATILES = RAFT_WINO4_ATILES;
+constexpr int LOAD_SLOT0 = 4, STORE_LAG = 6;   // halo item i: global load in slot LOAD_SLOT0 + i, LDS write STORE_LAG later
+static_assert(PF >= 1 && PF < NR, "prefetch distance must fit the fragment ring");
+static_assert(LOAD_SLOT0 + NA - 1 + STORE_LAG < 60, "halo writes must precede the chunk's barrier (slot 60)");
+// tap row of (phase, row-in-phase)
+__device__ __forceinline__ constexpr int tap_row(int ph, int row) { return ph == 0 ? 1 + row : (ph == 1 ? 3 + row : 5 * row); }
+}   // namespace wino4
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wunused-lambda-capture"
+template <int EPI>
+__global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
+    using namespace wino4;
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES, "winograd F(4x4) kernel: linear / relu / residual epilogues");
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int G = lane >> 4, LR = lane & 15;
+    const int rb = w & 1, cbp = w >> 1;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int ntn = p.npad / 64;
+    const int M = p.B * p.H * p.W;
+
+    int bid = blockIdx.x;   // XCD-aware remap (see conv_halo.h)
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = bid / ntn, nt = bid - mt * ntn;
+    const int tx0 = mt % tiles_x, ty0 = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
+    const int y0 = ty0 * TH, x0 = tx0 * TW;
+    const int n0 = nt * 64;
+    const int cin = p.c0 + p.c1;
+    const int nch = cin >> 4;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.a0, 0, (int)((((long)M - 1) * p.lda0 + p.c0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.wp, 0, (int)((long)36 * cin * p.npad * 4), 0x00020000);
+
+    // ---- halo staging: item = (halo pixel, 16-byte channel quad of the chunk)
+    int pix[NA], lds_off[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int item = tid + NTHR * i;
+        const int hp = item >> 2, c4 = item & 3;
+        const int hy = hp / HWP, hx = hp - hy * HWP;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = (hp < HP) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
+        pix[i] = ok ? (b * p.H + yy) * p.W + xx : -1;
+        lds_off[i] = hp < HP ? hy * RS + hx * 16 + (hx >> 2) * 4 + 2 * c4 : HH * RS;   // floats; second half at + 8
+    }
+    f32x4 ra[NA];
+    // source of a chunk (channels [0, c0) come from a0, the rest from a1): descriptor, leading dimension and channel base
+    // of the NEXT chunk are set once per chunk by next_source()
+    __amdgpu_buffer_rsrc_t rsn = rs0;
+    int ldn = p.lda0, chn = (tid & 3) * 4;
+    auto next_source = [&](int c) {
+        const int ch = c * 16;
+        const bool first = ch < p.c0, live = c < nch && !(RAFT_WINO4_ABL & 4);
+        const float *base = first ? p.a0 : (p.c1 ? p.a1 : p.a0);
+        const int ext = first ? (int)((((long)M - 1) * p.lda0 + p.c0) * 4) : (p.c1 ? (int)((((long)M - 1) * p.lda1 + p.c1) * 4) : 0);
+        rsn = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? ext : 0, 0x00020000);   // past the last chunk: empty
+        ldn = first ? p.lda0 : p.lda1;
+        chn = (first ? ch : ch - p.c0) + (tid & 3) * 4;
+    };
+    // branch-free: an out-of-image item has pix = -1, i.e. a byte offset far beyond any extent -> the bounds check returns 0
+    auto gload_item = [&](int i) { ra[i] = raft_buffer_load_f4(rsn, (unsigned)((pix[i] * ldn + chn) * 4)); };
+    auto lstore_item = [&](int i, int buf) {
+        float *dst = smem + buf * A_BUF + lds_off[i];
+        *(f32x2 *)dst = f32x2{ra[i][0], ra[i][1]};
+        *(f32x2 *)(dst + 8) = f32x2{ra[i][2], ra[i][3]};
+    };
+
+    // ---- fragments
+    const int a_lane = (4 * rb) * RS + 68 * LR + 2 * G;   // floats: patch origin of tile LR in row block rb, quad G
+    auto rd = [&](int buf, int r, int j, int h) -> f32x2 {
+        return *(const f32x2 *)(smem + buf * A_BUF + a_lane + r * RS + 16 * j + 4 * (j >> 2) + 8 * h);
+    };
+    // weights: packed in the order the loop consumes them, [chunk][slot q][k-quad G][n][2] (packing.py pack_conv_winograd4):
+    // the fragment of slot q for lane (G, n) is 8 bytes, the stream advances by one constant stride per slot
+    const unsigned b_lane = (unsigned)(((G * p.npad) + n0 + cbp * 32 + LR) * 8);   // bytes
+    const unsigned qstride = (unsigned)(4 * p.npad) * 8u;                          // bytes per slot
+    unsigned wrow = 0;                                                             // wave-uniform
+    f32x2 fb[NR][2];
+    auto frag_b = [&](int q) {   // called once per slot, in order: fetches the fragments of slot q (mod 72) of the stream
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            fb[q & (NR - 1)][j] = __builtin_bit_cast(
+                f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsw, (int)(b_lane + j * 128), (int)wrow, 0));
+        wrow += qstride;
+    };
+
+    // 72 accumulator tiles = 288 registers: the accumulator file holds 256, and hipcc picks ONE register class for every
+    // MFMA of a function (with the builtin it keeps all 72 tiles in AGPRs and shuffles the overflow through copies: 1584
+    // v_accvgpr moves per K chunk and scratch spills).  So the MFMAs are inline asm: taps 0..31 accumulate in AGPRs ("+a"),
+    // taps 32..35 in VGPRs ("+v").  hipcc pads no hazards of an asm statement (cdna_hip_programming.md 5.7): the two wait
+    // states between a VALU write of an operand and the MFMA are inside the string, the MFMA -> VALU read distance of the
+    // epilogue is the nop statement after the loop; accumulate chains (D = C) need none.
+    // tile index = tap * 2 + column block; tiles 0..W4_ATILES-1 in AGPRs, the rest in VGPRs (a few AGPRs are left to the
+    // register allocator: with all 256 taken it spills accumulators to scratch around the epilogue)
+#define X(i) f32x4 acc_##i = f32x4{0.f, 0.f, 0.f, 0.f};
+    W4_TILES(X)
+#undef X
+    int acc_end_ = 0;   // closes the explicit capture lists (implicit capture does not reach into discarded if-constexpr branches)
+#define X(i) &acc_##i,
+    auto mma = [W4_TILES(X) & acc_end_](auto tile, float a, float bw) {
+#undef X
+        constexpr int IDX = decltype(tile)::value;
+#define X(i)                                                                                                        \
+    if constexpr (IDX == i) {                                                                                      \
+        if constexpr (i < W4_ATILES)                                                                                    \
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc_##i) : "v"(a), "v"(bw));    \
+        else                                                                                                       \
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc_##i) : "v"(a), "v"(bw));    \
+    }
+        W4_TILES(X)
+#undef X
+    };
+#define X(i) &acc_##i,
+    auto acc_of = [W4_TILES(X) & acc_end_](auto tile) -> f32x4 {
+#undef X
+        constexpr int IDX = decltype(tile)::value;
+#define X(i) if constexpr (IDX == i) return acc_##i;
+        W4_TILES(X)
+#undef X
+    };
+
+    // ---- stage 1 of one phase, column j: raw[] = the patch rows the phase needs, Wn[row][j] = B^T rows of the phase
+    f32x2 W[2][2][6];     // [instance parity][row in phase][patch column]
+    f32x2 raw[6];
+    auto s1_read = [&](int buf, int ph, int j, int h) {
+        if (RAFT_WINO4_ABL & 2) return;
+        if (ph < 2) {
+#pragma unroll
+            for (int r = 1; r <= 4; ++r) raw[r] = rd(buf, r, j, h);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) raw[r] = rd(buf, r, j, h);
+        }
+    };
+    auto s1_calc = [&](int par, int ph, int j) {
+        if (RAFT_WINO4_ABL & 2) {
+            W[par][0][j] = W[par][1][j] = f32x2{1.f, 1.f};
+            return;
+        }
+        if (ph == 0) {
+            const f32x2 t1 = raw[4] - B2 * raw[2], t2 = raw[3] - B2 * raw[1];
+            W[par][0][j] = t1 + PA * t2;
+            W[par][1][j] = t1 - PA * t2;
+        } else if (ph == 1) {
+            const f32x2 t1 = raw[4] - A2 * raw[2], t2 = raw[3] - A2 * raw[1];
+            W[par][0][j] = t1 + PB * t2;
+            W[par][1][j] = t1 - PB * t2;
+        } else {
+            W[par][0][j] = (raw[4] - SS * raw[2]) + PP * raw[0];
+            W[par][1][j] = (raw[5] - SS * raw[3]) + PP * raw[1];
+        }
+    };
+    // ---- stage 2: V[tx] of a row from its W[0..5]; computed one tap ahead (pairs together)
+    f32x2 V[6];
+    auto s2_calc = [&](const f32x2 *wr, int tx) {   // fills V[tx] (and V[tx + 1] for the first tap of a pair)
+        if (tx == 0) {
+            V[0] = (wr[4] - SS * wr[2]) + PP * wr[0];
+        } else if (tx == 1) {
+            const f32x2 t1 = wr[4] - B2 * wr[2], t2 = wr[3] - B2 * wr[1];
+            V[1] = t1 + PA * t2;
+            V[2] = t1 - PA * t2;
+        } else if (tx == 3) {
+            const f32x2 t1 = wr[4] - A2 * wr[2], t2 = wr[3] - A2 * wr[1];
+            V[3] = t1 + PB * t2;
+            V[4] = t1 - PB * t2;
+        } else if (tx == 5) {
+            V[5] = (wr[5] - SS * wr[3]) + PP * wr[1];
+        }
+    };
+
+    // ---- prologue: chunk 0 into buffer 0, stage 1 of (chunk 0, half 0, phase 0), the first PF weight fragments, V[0]
+    next_source(0);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) gload_item(i);
+#pragma unroll
+    for (int q = 0; q < PF; ++q) frag_b(q);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) lstore_item(i, 0);
+    raft_barrier_lds();
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        s1_read(0, 0, j, 0);
+        s1_calc(0, 0, j);
+    }
+    s2_calc(W[0][0], 0);
+
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        next_source(c + 1);
+        w4_static_for<6>([&](auto inst_c) {
+            constexpr int inst = decltype(inst_c)::value;
+            constexpr int ph = inst % 3, par = inst & 1;
+            // the instance whose stage 1 runs under this one's MFMAs
+            constexpr int n_inst = (inst + 1) % 6, n_h = n_inst / 3, n_ph = n_inst % 3;
+            const int n_buf = inst == 5 ? buf ^ 1 : buf;
+            if (inst == 5) raft_barrier_lds();   // chunk c + 1 is in the other buffer; every read of this one has been consumed
+            w4_static_for<12>([&](auto u_c) {
+                constexpr int u = decltype(u_c)::value;
+                constexpr int row = u / 6, tx = u % 6;
+                constexpr int q = inst * 12 + u;
+                constexpr int t = tap_row(ph, row) * 6 + tx;
+                // quarter 0: weight fragments PF slots ahead
+                if (!(RAFT_WINO4_ABL & 1)) frag_b((q + PF) % 72);   // runs into the next chunk (past the last one: out of range, 0)
+                mma(std::integral_constant<int, 2 * t>{}, V[tx][0], fb[q & (NR - 1)][0][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                // quarter 1: stage 1 of the next instance -- LDS reads of column u / 2 in even slots, arithmetic in odd ones
+                // (unconditional: under the last chunk's last phase it transforms stale data that nobody uses -- a branch here
+                // lets the compiler sink the reads next to the arithmetic)
+                if ((u & 1) == 0)
+                    s1_read(n_buf, n_ph, u >> 1, n_h);
+                else
+                    s1_calc(par ^ 1, n_ph, u >> 1);
+                mma(std::integral_constant<int, 2 * t + 1>{}, V[tx][0], fb[q & (NR - 1)][1][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                // quarter 2: stage 2 one tap ahead (the next row after the last tap of a row)
+                if constexpr (u < 11) s2_calc(W[par][(u + 1) / 6], (u + 1) % 6);
+                mma(std::integral_constant<int, 2 * t>{}, V[tx][1], fb[q & (NR - 1)][0][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                // quarter 3: the next chunk's halo tile, one item per slot
+                {
+                    constexpr int li = q - LOAD_SLOT0, si = q - LOAD_SLOT0 - STORE_LAG;
+                    if (li >= 0 && li < NA) gload_item(li);
+                    if (si >= 0 && si < NA) lstore_item(si, buf ^ 1);
+                }
+                mma(std::integral_constant<int, 2 * t + 1>{}, V[tx][1], fb[q & (NR - 1)][1][1]);
+                if (u == 11) {
+                    // V[0] of the next instance's first row: its W is complete now (column 5 was finished in this slot)
+                    s2_calc(W[par ^ 1][0], 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    }
+
+    // the last MFMAs' results must have left the matrix pipe before a VALU reads them (8-pass MFMA: 12 wait states)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: lane owns channel n; register r of an accumulator is tile 4G + r of the row block
+    constexpr bool HAS_E0 = EPI == EPI_RES;
+    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.o0, 0, (int)((((long)M - 1) * p.ldo0 + p.nvalid) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t re0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(HAS_E0 ? (const void *)p.e0 : (const void *)p.o0), 0,
+        HAS_E0 ? (int)((((long)M - 1) * p.lde0 + p.nvalid) * 4) : 0, 0x00020000);
+    auto bstore = [](float v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, soff, 0);
+    };
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+    };
+    const bool interior = (y0 + TH <= p.H) & (x0 + TW <= p.W);   // wave-uniform
+    // the epilogue's lane indices are re-derived from an opaque copy of the thread id: otherwise hipcc evaluates the
+    // epilogue's addresses before the K loop and carries them through it in registers the loop does not have (spills)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int G_e = (tid_e >> 4) & 3, LR_e = tid_e & 15, rb_e = (tid_e >> 6) & 1, cbp_e = tid_e >> 7;
+    const int xb = x0 + 16 * G_e;                                // the lane's tiles 4G + r: pixels xb + 4 r + jx
+    unsigned bo[4], be[4];
+    bool rowok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = y0 + 4 * rb_e + i;
+        const unsigned pix0 = (unsigned)((b * p.H + yy) * p.W + xb);
+        bo[i] = pix0 * p.ldo0 * 4u;
+        be[i] = HAS_E0 ? pix0 * p.lde0 * 4u : 0u;
+        rowok[i] = yy < p.H;
+    }
+    w4_static_for<2>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+        const int n = n0 + (cbp_e * 2 + j) * 16 + LR_e;
+        const bool nok = n < p.nvalid;                                      // channel beyond nvalid: every access out of range
+        const float bias = p.bias[n];                                       // bias has npad entries
+        // A^T over the tap rows, one tap column at a time (whole tiles: the four registers of an accumulator are read
+        // together): T[i][tx]
+        f32x4 T[4][6];
+        w4_static_for<6>([&](auto tx_c) {
+            constexpr int tx = decltype(tx_c)::value;
+            const f32x4 m0 = acc_of(std::integral_constant<int, 2 * tx + j>{}),
+                        m1 = acc_of(std::integral_constant<int, 2 * (6 + tx) + j>{}),
+                        m2 = acc_of(std::integral_constant<int, 2 * (12 + tx) + j>{}),
+                        m3 = acc_of(std::integral_constant<int, 2 * (18 + tx) + j>{}),
+                        m4 = acc_of(std::integral_constant<int, 2 * (24 + tx) + j>{}),
+                        m5 = acc_of(std::integral_constant<int, 2 * (30 + tx) + j>{});
+            const f32x4 sa = m1 + m2, da = m1 - m2, sb = m3 + m4, db = m3 - m4;
+            T[0][tx] = m0 + (sa + sb);
+            T[1][tx] = PA * da + PB * db;
+            T[2][tx] = A2 * sa + B2 * sb;
+            T[3][tx] = (A3 * da + B3 * db) + m5;
+            __builtin_amdgcn_sched_barrier(0);   // keeps the accumulator reads of later columns from being hoisted (registers)
+        });
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 sa = T[i][1] + T[i][2], da = T[i][1] - T[i][2], sb = T[i][3] + T[i][4], db = T[i][3] - T[i][4];
+            f32x4 Y[4];
+            Y[0] = T[i][0] + (sa + sb);
+            Y[1] = PA * da + PB * db;
+            Y[2] = A2 * sa + B2 * sb;
+            Y[3] = (A3 * da + B3 * db) + T[i][5];
+            // element (r, jx) = pixel xb + 4 r + jx of row y0 + 4 rb + i: wave-uniform byte offset from the lane base; tiles cut
+            // by the image border (`interior` false, wave-uniform) add the per-element out-of-range bit
+            const unsigned vo = nok ? bo[i] + (unsigned)n * 4u : RAFT_OOB, ve = nok ? be[i] + (unsigned)n * 4u : RAFT_OOB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float xv[4];
+                if (HAS_E0) {
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        const unsigned dead = (interior | (rowok[i] & (xb + 4 * r + jx < p.W))) ? 0u : RAFT_OOB;
+                        xv[jx] = bload(re0, ve | dead, (4 * r + jx) * p.lde0 * 4);
+                    }
+                }
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    float v = Y[jx][r] + bias;
+                    if (EPI == EPI_RES) {
+                        v = fmaxf(xv[jx] + fmaxf(v, 0.f), 0.f);
+                    } else {
+                        if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                        v *= p.scale;
+                    }
+                    if ((RAFT_WINO4_ABL & 8) && v != 12345.678f) continue;
+                    const unsigned dead = (interior | (rowok[i] & (xb + 4 * r + jx < p.W))) ? 0u : RAFT_OOB;
+                    bstore(v, ro0, vo | dead, (4 * r + jx) * p.ldo0 * 4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+}
+
+#pragma clang diagnostic pop
+
+// launcher (conv_wino4.hip); `a.wp` holds the F(4x4, 3x3)-transformed weights in consumption order
+// (Cin/16, 72, 4, npad, 2) -- tf_raft_amd/packing.py pack_conv_winograd4.  epi: EPI_LINEAR / EPI_RELU / EPI_RES.
+int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s);

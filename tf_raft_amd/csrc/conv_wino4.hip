@@ -1,0 +1,26 @@
+// Winograd F(4x4, 3x3) convolution launcher (kernel: conv_wino4.h).
+#include "conv_wino4.h"
+
+int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s) {
+    if (a.c0 <= 0 || a.c0 % 16 || a.c1 < 0 || a.c1 % 16 || a.npad <= 0 || a.npad % 64) return RAFT_E_UNSUPPORTED;
+    if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
+    if (!raft_aligned16(a.a0) || !raft_aligned16(a.wp) || (a.c1 && !raft_aligned16(a.a1))) return RAFT_E_ALIGN;
+    if (a.init || a.pre_scale || a.stats || (a.Hi && (a.Hi != a.H || a.Wi != a.W))) return RAFT_E_UNSUPPORTED;
+    if (epi == EPI_RES && a.e0 == nullptr) return RAFT_E_NULL;
+    {   // 32-bit buffer offsets: every operand must span < 2 GiB
+        const int64_t M = (int64_t)a.B * a.H * a.W, lim = (int64_t)1 << 31;
+        if (((M - 1) * a.lda0 + a.c0) * 4 >= lim || (a.c1 && ((M - 1) * a.lda1 + a.c1) * 4 >= lim)) return RAFT_E_UNSUPPORTED;
+        if (M * a.ldo0 * 4 >= lim || (int64_t)36 * (a.c0 + a.c1) * a.npad * 4 >= lim) return RAFT_E_UNSUPPORTED;
+        if (epi == EPI_RES && M * a.lde0 * 4 >= lim) return RAFT_E_UNSUPPORTED;
+    }
+    const int grid = a.B * ((a.H + 7) / 8) * ((a.W + 63) / 64) * (a.npad / 64);
+    if (epi == EPI_LINEAR)
+        conv_wino4_kernel<EPI_LINEAR><<<grid, 256, 0, s>>>(a);
+    else if (epi == EPI_RELU)
+        conv_wino4_kernel<EPI_RELU><<<grid, 256, 0, s>>>(a);
+    else if (epi == EPI_RES)
+        conv_wino4_kernel<EPI_RES><<<grid, 256, 0, s>>>(a);
+    else
+        return RAFT_E_UNSUPPORTED;
+    return raft_launch_status();
+}

@@ -83,6 +83,122 @@ def pack_conv_winograd(kernel: np.ndarray, bias: np.ndarray,
     return pack_conv(winograd_kernel(kernel), bias, sources)
 
 
+# Winograd F(4x4, 3x3), interpolation points {0, +-5/8, +-3/2, inf} (csrc/conv_wino4.h).  Point order = tap order
+# [0, +a, -a, +b, -b, inf].  Cook-Toom construction: A^T[j][i] = p_i^j (+ the x^(m-1) row of infinity), G[i][k] = p_i^k / N_i
+# with N_i = prod_{j != i}(p_i - p_j), B^T[i] = coefficients of prod_{j != i}(x - p_j) (infinity: of prod_j (x - p_j)).
+# The points were chosen by measured fp32 error against the float64 convolution (tools/study/wino_error.py): rms 1.1e-6
+# at K = 256 against 2.3e-6 for the textbook {0, +-1, +-2} and 3.8e-7 for F(2x2, 3x3).
+WINO4_A, WINO4_B = 0.625, 1.5
+
+
+def cook_toom(points, m: int, r: int):
+    """(A^T (m, n), G (n, r), B^T (n, n)) in float64, exact rational arithmetic inside, for the finite `points`
+    (n - 1 of them, n = m + r - 1) plus the point at infinity (last row / column)."""
+    from fractions import Fraction as Fr
+    n = m + r - 1
+    if len(points) != n - 1:
+        raise ValueError(f'F({m}, {r}) needs {n - 1} finite points, got {len(points)}')
+    pts = [Fr(x) for x in points]
+
+    def polymul(a, b):
+        out = [Fr(0)] * (len(a) + len(b) - 1)
+        for i, x in enumerate(a):
+            for j, y in enumerate(b):
+                out[i + j] += x * y
+        return out
+    at = [[pts[i] ** j for i in range(n - 1)] + [Fr(int(j == m - 1))] for j in range(m)]
+    g, bt = [], []
+    for i in range(n - 1):
+        norm, poly = Fr(1), [Fr(1)]
+        for j in range(n - 1):
+            if j != i:
+                norm *= pts[i] - pts[j]
+                poly = polymul(poly, [-pts[j], Fr(1)])
+        g.append([pts[i] ** k / norm for k in range(r)])
+        bt.append(poly + [Fr(0)] * (n - len(poly)))
+    poly = [Fr(1)]
+    for j in range(n - 1):
+        poly = polymul(poly, [-pts[j], Fr(1)])
+    g.append([Fr(0)] * (r - 1) + [Fr(1)])
+    bt.append(poly)
+    as_f64 = lambda mat: np.array([[float(x) for x in row] for row in mat], dtype=np.float64)
+    return as_f64(at), as_f64(g), as_f64(bt)
+
+
+WINO4_AT, _WINO4_G, WINO4_BT = cook_toom((0, WINO4_A, -WINO4_A, WINO4_B, -WINO4_B), 4, 3)
+
+
+def winograd4_kernel(kernel: np.ndarray) -> np.ndarray:
+    """(3, 3, Cin, Cout) -> (6, 6, Cin, Cout): U[ty, tx] = sum_{u,v} G[ty, u] G[tx, v] g[u, v] in float64, rounded once."""
+    k = np.asarray(kernel, dtype=np.float64)
+    if k.shape[:2] != (3, 3):
+        raise ValueError(f'winograd4_kernel expects a 3x3 kernel, got {k.shape[:2]}')
+    return np.einsum('au,bv,uvio->abio', _WINO4_G, _WINO4_G, k).astype(np.float32)
+
+
+def wino4_tap_of_slot(q: int):
+    """Slot q (0..71) of a 16-channel chunk in conv_wino4_kernel -> (tap row, tap column, half): the loop walks two halves
+    (k-steps 2h, 2h + 1), each three phases of two tap rows -- (+a, -a), (+b, -b), (0, inf) -- of six taps."""
+    inst, u = divmod(q, 12)
+    h, ph = divmod(inst, 3)
+    row, tx = divmod(u, 6)
+    ty = (1 + row) if ph == 0 else ((3 + row) if ph == 1 else 5 * row)
+    return ty, tx, h
+
+
+def pack_conv_winograd4(kernel: np.ndarray, bias: np.ndarray,
+                        sources: Sequence[Tuple[int, int]] = None) -> Tuple[np.ndarray, np.ndarray, int]:
+    """F(4x4, 3x3)-transformed kernel in the order ``conv_wino4_kernel`` (csrc/conv_wino4.h) consumes it:
+    wp float32[Kpad/16, 72, 4, npad, 2] = [16-channel chunk][slot q][k-quad G][n][e] holding
+    U[tap(q)][16 c + 4 G + 2 h(q) + e][n] -- a wave's weight stream is one constant stride per slot.
+    ``sources`` as in ``pack_conv`` (padded channel counts: multiples of 16).  Returns (wp, bias[npad], npad)."""
+    u = winograd4_kernel(kernel)
+    _, _, cin, cout = u.shape
+    if sources is None:
+        sources = [(cin, round_up(cin, 16))]
+    if sum(c for c, _ in sources) != cin:
+        raise ValueError(f'sources {sources} do not add up to Cin={cin}')
+    for _, cp in sources:
+        if cp % 16:
+            raise ValueError('padded source channel counts must be multiples of 16')
+    kpad = sum(cp for _, cp in sources)
+    npad = round_up(cout, 64)
+    full = np.zeros((6, 6, kpad, npad), dtype=np.float32)
+    k_src = k_dst = 0
+    for c, cp in sources:
+        full[:, :, k_dst:k_dst + c, :cout] = u[:, :, k_src:k_src + c, :]
+        k_src += c
+        k_dst += cp
+    nch = kpad // 16
+    wp = np.zeros((nch, 72, 4, npad, 2), dtype=np.float32)
+    for q in range(72):
+        ty, tx, h = wino4_tap_of_slot(q)
+        blk = full[ty, tx].reshape(nch, 4, 4, npad)                       # [chunk][G][channel in quad][n]
+        wp[:, q] = blk[:, :, 2 * h:2 * h + 2, :].transpose(0, 1, 3, 2)    # [chunk][G][n][e]
+    b = np.zeros((npad,), dtype=np.float32)
+    b[:cout] = np.asarray(bias, dtype=np.float32)
+    return wp, b, npad
+
+
+def wino4_transform_6(d, a: float = WINO4_A, b: float = WINO4_B):
+    """The 6-point transform B^T d along axis 0 exactly as conv_wino4.h evaluates it (pairs +-a, +-b share their even /
+    odd parts): returns rows in tap order [0, +a, -a, +b, -b, inf].  Works on any array type with + - * (tests feed
+    float32 to predict the kernel's rounding)."""
+    a2, b2 = a * a, b * b
+    s, p = a2 + b2, a2 * b2
+    r0 = (d[4] - s * d[2]) + p * d[0]
+    ta1, ta2 = d[4] - b2 * d[2], d[3] - b2 * d[1]
+    tb1, tb2 = d[4] - a2 * d[2], d[3] - a2 * d[1]
+    r5 = (d[5] - s * d[3]) + p * d[1]
+    return [r0, ta1 + a * ta2, ta1 - a * ta2, tb1 + b * tb2, tb1 - b * tb2, r5]
+
+
+def wino4_output_4(mm, a: float = WINO4_A, b: float = WINO4_B):
+    """A^T m along axis 0 (6 taps in tap order -> 4 outputs) as conv_wino4.h evaluates it."""
+    sa, da, sb, db = mm[1] + mm[2], mm[1] - mm[2], mm[3] + mm[4], mm[3] - mm[4]
+    return [mm[0] + (sa + sb), a * da + b * db, (a * a) * sa + (b * b) * sb, ((a * a * a) * da + (b * b * b) * db) + mm[5]]
+
+
 # 1-D Winograd F(2, 5), points {0, +-1, +-1/2, inf}, rows rescaled by powers of two (csrc/conv_wino1d.h): U = G' g
 _WINO1D_G = np.array([[1.0, 0.0, 0.0, 0.0, 0.0],
                       [1 / 6, 1 / 6, 1 / 6, 1 / 6, 1 / 6],
@@ -223,6 +339,14 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     wp, bb, npad = pack_convc1_fused(w[f'{p}/encoder/convc1/kernel'], w[f'{p}/encoder/convc1/bias'])
     out.append(('convc1_f', wp, bb, npad))
     out = out + ctx_w4
+    # Winograd F(4x4, 3x3) copies (csrc/conv_wino4.h); field order of the C struct
+    k, b = fuse_n(w, [f'{p}/flow_head/conv1', f'{p}/mask/0'])
+    for field, kk, bb_ in (('convc2_w44', w[f'{p}/encoder/convc2/kernel'], w[f'{p}/encoder/convc2/bias']),
+                           ('conv_w44', w[f'{p}/encoder/conv/kernel'], w[f'{p}/encoder/conv/bias']),
+                           ('fh1_mask0_w44', k, b),
+                           ('fh1_w44', w[f'{p}/flow_head/conv1/kernel'], w[f'{p}/flow_head/conv1/bias'])):
+        wp, bb, npad = pack_conv_winograd4(kk, bb_)
+        out.append((field, wp, bb, npad))
     return out
 
 
