@@ -52,23 +52,28 @@ STAGES = ['corr_lookup', 'convc1', 'convc2', 'convf1', 'convf2', 'conv', 'gru_zr
 
 
 # Layers that run on a Winograd kernel execute fewer multiplies than the convolution they compute: F(2x2, 3x3) 16 per
-# 36 (conv_wino.h), F(2, 5) 6 per 10 and F(4, 5) 8 per 20 (conv_wino1d.h).  roofline.achieved counts the FLOPs EXECUTED on
+# 36 (conv_wino.h), F(4x4, 3x3) 36 per 144 (conv_wino4.h), F(2, 5) 6 per 10 and F(4, 5) 8 per 20 (conv_wino1d.h).  roofline.achieved counts the FLOPs EXECUTED on
 # the MFMA pipe (direct FLOPs / this factor); the direct-convolution figure is kept as algorithmic_tflops.
-WINOGRAD_ALGORITHMS = {2.25: 'Winograd F(2x2,3x3)', 10.0 / 6.0: 'Winograd F(2,5)', 2.5: 'Winograd F(4,5)'}
+WINOGRAD_ALGORITHMS = {2.25: 'Winograd F(2x2,3x3)', 4.0: 'Winograd F(4x4,3x3)', 10.0 / 6.0: 'Winograd F(2,5)', 2.5: 'Winograd F(4,5)'}
 
 
-def winograd_layers():
+def winograd_layers(pairs=4):
     """{stage name: direct MACs / executed MACs} of the stages that are on a Winograd kernel under the current
-    RAFT_CONV_WINO / RAFT_GRU_WINO / RAFT_GRU_WINO4 switches (defaults of csrc/conv.hip: 3x3 mask 13 = convc2 | conv |
-    fh1_mask0, GRU masks 15: F(4, 5) where its bit is set, else F(2, 5))."""
+    RAFT_CONV_WINO / RAFT_CONV_WINO4 / RAFT_GRU_WINO / RAFT_GRU_WINO4 switches (defaults of csrc/conv.hip: F(2x2,3x3) mask
+    13 = convc2 | conv | fh1_mask0; F(4x4,3x3) mask 8 = fh1_mask0, + 1 = convc2 from 8 pairs per launch on; GRU masks 15:
+    F(4, 5) where its bit is set, else F(2, 5))."""
     from tf_raft_amd import _ffi
     m3 = int(_ffi.get_option('RAFT_CONV_WINO') or 13)
+    m44 = _ffi.get_option('RAFT_CONV_WINO4')
+    m44 = int(m44) if m44 else (8 | (1 if pairs >= 8 else 0))
     mg = int(_ffi.get_option('RAFT_GRU_WINO') or 15)
     mg4 = int(_ffi.get_option('RAFT_GRU_WINO4') or 15)
     on = {}
     for bit, name in ((1, 'convc2'), (2, 'convf2'), (4, 'conv'), (8, 'fh1_mask0')):
         if m3 & bit:
             on[name] = 2.25
+        if (m44 & bit) and name != 'convf2':
+            on[name] = 4.0
     for bit, name in ((1, 'gru_zr1'), (2, 'gru_q1'), (4, 'gru_zr2'), (8, 'gru_q2')):
         if mg4 & bit:
             on[name] = 2.5
@@ -447,7 +452,7 @@ def main():
         copy_gbs = measured_copy_gbs(device, _dev.lib(), _dev, _ffi.check)
         result['hbm_copy_gbs_measured'] = round(copy_gbs, 1)
 
-        wl = winograd_layers()
+        wl = winograd_layers(B)
         if dom in flops:
             ratio = wl.get(dom, 1.0)                          # direct MACs / MACs issued on the MFMA pipe
             alg = flops[dom] / (stage_ms[dom] * 1e-3) / 1e12

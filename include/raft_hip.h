@@ -29,7 +29,7 @@
  *   RAFT_CONV_DEEP      0/1  deep weight prefetch of the single-column-block halo tiles          (default 1)
  *   RAFT_CONV_WINO      bit mask {1 convc2, 2 convf2, 4 conv, 8 fh1_mask0}: layers on the F(2x2,3x3) kernel (13)
  *   RAFT_CONV_WINO4     the same mask for the F(4x4,3x3) kernel, preferred where its bit is set and the 6x6-tap weights
- *                       were supplied                                                             (default 8: fh1_mask0)
+ *                       were supplied                                    (default 8: fh1_mask0; + 1: convc2 from 8 pairs on)
  *   RAFT_SMALL_WINO     bit mask {1 conv, 2 gru_zr, 4 gru_q, 8 fh1} of the SmallUpdateBlock      (default 15)
  *   RAFT_GRU_WINO       bit mask {1 zr1, 2 q1, 4 zr2, 8 q2}: SepConvGRU layers on F(2,5)         (default 15)
  *   RAFT_GRU_WINO4      the same mask for F(4,5), preferred where both bits are set              (default 15)
@@ -192,7 +192,7 @@ int raft_conv2d_winograd_f32(const float *a0, int lda0, int c0, const float *a1,
 
 /* The same by Winograd F(4x4, 3x3) (36 multiplies per 16 outputs: 4x fewer than the direct kernel, 1.78x fewer than
  * F(2x2, 3x3); fp32, points {0, +-5/8, +-3/2, inf}; deviation from the float64 convolution ~3x that of F(2x2, 3x3)).
- * `wp` = the transformed kernel in the consumption order of the kernel, (Cin/16, 72, 4, npad, 2) -- packing.py
+ * `wp` = the transformed kernel in the consumption order of the kernel, (Cin/16, 72, 4, npad/32, 16, 2, 2) -- packing.py
  * pack_conv_winograd4; c0, c1 multiples of 16, npad a multiple of 64. */
 int raft_conv2d_winograd4_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
                               const float *wp, const float *bias, int B, int H, int W, int npad,

@@ -40,19 +40,22 @@ def test_winograd_layers_follow_the_library_switches():
     """roofline.achieved counts EXECUTED MFMA FLOPs: direct FLOPs / {2.25, 2.5, 10/6} for the layers that are on a Winograd
     kernel under the current switches, so that frac <= 1 (the headline frac was 1.30)."""
     from tf_raft_amd import _ffi
-    saved = {k: _ffi.get_option(k) for k in ('RAFT_CONV_WINO', 'RAFT_GRU_WINO', 'RAFT_GRU_WINO4')}
+    saved = {k: _ffi.get_option(k) for k in ('RAFT_CONV_WINO', 'RAFT_CONV_WINO4', 'RAFT_GRU_WINO', 'RAFT_GRU_WINO4')}
     try:
         for k in saved:
             _ffi.set_option(k, None)
         d = bench.winograd_layers()
-        assert d == {'convc2': 2.25, 'conv': 2.25, 'fh1_mask0': 2.25, 'gru_zr1': 2.5, 'gru_q1': 2.5, 'gru_zr2': 2.5,
-                     'gru_q2': 2.5}
+        assert d == {'convc2': 2.25, 'conv': 2.25, 'fh1_mask0': 4.0, 'gru_zr1': 2.5, 'gru_q1': 2.5, 'gru_zr2': 2.5,
+                     'gru_q2': 2.5}                               # F(4x4,3x3): the flow / mask head by default ...
+        assert bench.winograd_layers(8)['convc2'] == 4.0          # ... and convc2 from 8 pairs per launch on
+        _ffi.set_option('RAFT_CONV_WINO4', 0)
+        assert bench.winograd_layers(8)['convc2'] == 2.25 and bench.winograd_layers()['fh1_mask0'] == 2.25
         _ffi.set_option('RAFT_GRU_WINO4', 0)
         assert bench.winograd_layers()['gru_zr1'] == pytest.approx(10.0 / 6.0)
         _ffi.set_option('RAFT_GRU_WINO', 0)
         _ffi.set_option('RAFT_CONV_WINO', 8)
         assert bench.winograd_layers() == {'fh1_mask0': 2.25}
-        assert set(bench.WINOGRAD_ALGORITHMS) == {2.25, 2.5, 10.0 / 6.0}
+        assert set(bench.WINOGRAD_ALGORITHMS) == {2.25, 4.0, 2.5, 10.0 / 6.0}
     finally:
         for k, v in saved.items():
             _ffi.set_option(k, v if v != '' else None)

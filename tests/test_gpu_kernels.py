@@ -413,7 +413,7 @@ def test_conv2d_winograd4_matches_oracle(rng, shape):
         buf[..., :arr.shape[-1]] = arr
         srcs.append(_dev.to_device(buf))
     wp, b, npad = packing.pack_conv_winograd4(kernel, bias, [(c_a, 48), (c_b, 64)])
-    assert wp.shape == (7, 72, 4, npad, 2) and npad == 192
+    assert wp.shape == (7, 72, 4, npad // 32, 16, 2, 2) and npad == 192
     wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
     out = torch.full((B, H, W, cout), float('nan'), device=srcs[0].device)
     check(_dev.lib().raft_conv2d_winograd4_f32(_dev.ptr(srcs[0]), 48, 48, _dev.ptr(srcs[1]), 64, 64, _dev.ptr(wp_d),

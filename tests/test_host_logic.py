@@ -469,7 +469,8 @@ def _wino4_emulate(x, wp, bias, cout):
     the tap (row, column, half) of packing.wino4_tap_of_slot, V = B^T d B by the kernel's two stages (fp32), products
     accumulated per tap in fp32, A^T . A at the end.  x: (H, W, Cpad) with H, W multiples of 4."""
     H, W, cpad = x.shape
-    nch, npad = wp.shape[0], wp.shape[3]
+    nch, npad = wp.shape[0], wp.shape[3] * 32
+    wq = wp.transpose(0, 1, 2, 6, 3, 5, 4).reshape(nch, 72, 4, 2, npad)            # [chunk][slot][G][e][n]
     xp = np.zeros((H + 2, W + 2, cpad), np.float32)
     xp[1:-1, 1:-1] = x
     out = np.zeros((H, W, cout), np.float32)
@@ -485,7 +486,7 @@ def _wino4_emulate(x, wp, bias, cout):
                     for g in range(4):
                         for e in range(2):
                             ch = 16 * c + 4 * g + 2 * h + e
-                            acc[ty, tx] += v[ty, tx, ch] * wp[c, q, g, :, e]
+                            acc[ty, tx] += v[ty, tx, ch] * wq[c, q, g, e]
             t = np.stack(packing.wino4_output_4([acc[i] for i in range(6)]))                 # over tap rows: [i][tx][n]
             y = np.stack(packing.wino4_output_4([t[:, j] for j in range(6)]), axis=1)        # [i][jx][n]
             out[ty0:ty0 + 4, tx0:tx0 + 4] = y[:, :, :cout] + bias[:cout]
@@ -514,7 +515,7 @@ def test_winograd4_transforms_and_packed_stream_reproduce_the_convolution(rng):
     kernel = (rng.normal(size=(3, 3, c_a + c_b, cout)) * 0.2).astype(np.float32)
     bias = rng.normal(size=cout).astype(np.float32)
     wp, b, npad = packing.pack_conv_winograd4(kernel, bias, [(c_a, 32), (c_b, 16)])
-    assert wp.shape == (3, 72, 4, 64, 2) and npad == 64 and wp.dtype == np.float32
+    assert wp.shape == (3, 72, 4, 2, 16, 2, 2) and npad == 64 and wp.dtype == np.float32
     xa, xb = rng.normal(size=(8, 12, c_a)).astype(np.float32), rng.normal(size=(8, 12, c_b)).astype(np.float32)
     x = np.zeros((8, 12, 48), np.float32)
     x[..., :c_a], x[..., 32:] = xa, xb

@@ -261,11 +261,15 @@ static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weig
 // B = 4).  Read per call so that tests can switch it.
 constexpr int RAFT_WINO_DEFAULT = 13;
 constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr, 4: gru_q, 8: fh1}, switch RAFT_SMALL_WINO
-constexpr int RAFT_WINO4_DEFAULT = 8;          // F(4x4, 3x3): {1: convc2, 4: conv, 8: fh1_mask0 / fh1}, switch RAFT_CONV_WINO4
+// F(4x4, 3x3) (conv_wino4.h), switch RAFT_CONV_WINO4 = bit mask {1: convc2, 4: conv, 8: fh1_mask0 / fh1}.  Default: the flow /
+// mask head at every size (N = 512: 224 workgroups of 8 x 64 pixels x 64 channels at B = 4 -- 62 us against 88 for F(2x2,3x3),
+// profiles/r07e_wino4_ablation.txt), convc2 (N = 192) from 8 pairs on, where its 2-row-block x 64-channel workgroups are enough
+// to cover the chip (B = 4: 84 workgroups for 256 CUs, slower than F(2x2,3x3)); conv (N = 128) never by default.
+static int wino4_default_mask(const ConvArgs &a) { return 8 | ((int64_t)a.B * a.H * a.W >= 8 * 3584 ? 1 : 0); }
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
                           hipStream_t s, bool small = false, const raft_conv_weights *wino44 = nullptr) {
     const int mask = small ? raft_opt(RAFT_OPT_SMALL_WINO, RAFT_SMALL_WINO_DEFAULT) : raft_opt(RAFT_OPT_CONV_WINO, RAFT_WINO_DEFAULT);
-    if (wino44 != nullptr && wino44->wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, RAFT_WINO4_DEFAULT) & bit) &&
+    if (wino44 != nullptr && wino44->wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, wino4_default_mask(a)) & bit) &&
         (epi == EPI_LINEAR || epi == EPI_RELU || epi == EPI_RES)) {
         a.wp = wino44->wp;
         a.bias = wino44->bias;
@@ -735,7 +739,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         RAFT_TRY(launch_conv3x3(wts->fh1_mask0, wts->fh1_mask0_w, 8, a, EPI_RELU, s, false, &wts->fh1_mask0_w44));
         RAFT_MARK();
     } else {           // relu(flow_head.conv1(net)) only            3x3, 128 -> 256        -> fm[:, 0:256]
-        const bool w44 = wts->fh1_w44.wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, RAFT_WINO4_DEFAULT) & 8);
+        const bool w44 = wts->fh1_w44.wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, 8) & 8);
         ConvArgs a = conv_args(w44 ? wts->fh1_w44 : wts->fh1_w, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 256, fm, 512);
         RAFT_TRY(w44 ? raft_launch_conv_wino4(a, EPI_RELU, s) : raft_launch_conv_wino(a, EPI_RELU, s));
     }

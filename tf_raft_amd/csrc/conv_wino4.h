@@ -37,6 +37,20 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #include <type_traits>
 #include <utility>
 
+// two channels of a lane in the transforms.  Default: a 2-vector (hipcc emits v_pk_fma_f32); RAFT_WINO4_SCALAR (tools/ablate,
+// together with -fno-slp-vectorize): a pair of scalars (v_fma_f32), to price packed against scalar VALU beside the MFMAs
+#ifdef RAFT_WINO4_SCALAR
+struct alignas(8) w4v2 {
+    float x, y;
+    __device__ __forceinline__ float operator[](int i) const { return i ? y : x; }
+};
+__device__ __forceinline__ w4v2 operator+(w4v2 a, w4v2 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ w4v2 operator-(w4v2 a, w4v2 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ w4v2 operator*(float k, w4v2 a) { return {k * a.x, k * a.y}; }
+#else
+typedef f32x2 w4v2;
+#endif
+
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  The accumulator
 // of a tap is selected in the FRONT END (if constexpr over named variables): one array of 72 tiles is never promoted to
 // registers by hipcc (too many uses of one alloca), and a switch over 72 cases x 288 call sites is not unrolled.
@@ -48,20 +62,33 @@ template <int N, class F>
 __device__ __forceinline__ void w4_static_for(F &&f) {
     w4_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
-#define W4_TILES(X)                                                                                                      \
+#define W4_TAPS(X)                                                                                                       \
     X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21)   \
-    X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41)    \
-    X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61)    \
-    X(62) X(63) X(64) X(65) X(66) X(67) X(68) X(69) X(70) X(71)
+    X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35)
 
 #ifndef RAFT_WINO4_PF
 #define RAFT_WINO4_PF 4      // weight fragments are fetched this many tap slots (4 MFMAs each) ahead
 #endif
-#ifndef RAFT_WINO4_ATILES
-#define RAFT_WINO4_ATILES 62  // accumulator tiles (of 72) kept in AGPRs
+#ifdef RAFT_WINO4_NOSB        // tools/ablate: leave the order of the slot bodies to the compiler
+#define W4_SB()
+#else
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef RAFT_WINO4_NOSNOP      // tools/ablate: MFMA statements without their leading wait states (timing only: may miscompute)
+#define W4_PAD ""
+#else
+#define W4_PAD "s_nop 1\n\t"
+#endif
+// the four MFMAs of a tap slot: %0 / %1 = the tap's accumulator tiles (column block 0 / 1), %2 %3 = V (k-steps 2h, 2h + 1),
+// %4 %5 = weights of column block 0, %6 %7 = of column block 1
+#define W4_MFMA4                                                                                                          \
+    W4_PAD "v_mfma_f32_16x16x4_f32 %0, %2, %4, %0\n\tv_mfma_f32_16x16x4_f32 %1, %2, %6, %1\n\t"                          \
+           "v_mfma_f32_16x16x4_f32 %0, %3, %5, %0\n\tv_mfma_f32_16x16x4_f32 %1, %3, %7, %1"
+#ifndef RAFT_WINO4_ATAPS
+#define RAFT_WINO4_ATAPS 31   // taps (of 36; two accumulator tiles each) whose accumulators are kept in AGPRs
 #endif
 #ifndef RAFT_WINO4_ABL
-#define RAFT_WINO4_ABL 0     // tools/ablate: 1 no weight loads in the loop, 2 no stage 1, 4 no halo staging, 8 no stores
+#define RAFT_WINO4_ABL 0     // tools/ablate: 1 no weight loads in the loop, 2 no stage 1, 4 no halo staging, 8 no stores, 16 no stage 2
 #endif
 
 namespace wino4 {
@@ -73,8 +100,11 @@ constexpr int A_BUF = HH * RS + 16;            // + one dummy pixel for the padd
 constexpr int NTHR = 256;
 constexpr int NA = (HP * 4 + NTHR - 1) / NTHR; // 16-byte items per thread per chunk (11)
 constexpr int PF = RAFT_WINO4_PF, NR = 8;
-constexpr int W4_ATILES = RAFT_WINO4_ATILES;
-constexpr int LOAD_SLOT0 = 4, STORE_LAG = 6;   // halo item i: global load in slot LOAD_SLOT0 + i, LDS write STORE_LAG later
+constexpr int W4_ATAPS = RAFT_WINO4_ATAPS;
+#ifndef RAFT_WINO4_LAG
+#define RAFT_WINO4_LAG 12
+#endif
+constexpr int LOAD_SLOT0 = 0, STORE_LAG = RAFT_WINO4_LAG;   // halo item i: global load in slot LOAD_SLOT0 + i, LDS write STORE_LAG later
 static_assert(PF >= 1 && PF < NR, "prefetch distance must fit the fragment ring");
 static_assert(LOAD_SLOT0 + NA - 1 + STORE_LAG < 60, "halo writes must precede the chunk's barrier (slot 60)");
 // tap row of (phase, row-in-phase)
@@ -101,7 +131,23 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
         const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int mt = bid / ntn, nt = bid - mt * ntn;
+    int mt = bid / ntn, nt = bid - mt * ntn;
+#ifdef RAFT_WINO4_XCD
+    // experiment: one channel group (or a set of them) per XCD, so that an XCD's L2 holds 1/8 of the transformed weights and
+    // every pixel tile of that group runs on it (hardware places workgroup b on XCD b % 8)
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        if ((nwg & 7) == 0 && (ntn & 7) == 0) {
+            const int per = ntn >> 3;
+            nt = xcd + 8 * (idx % per);
+            mt = idx / per;
+        } else if ((nwg & 7) == 0 && 8 % ntn == 0) {
+            const int g = 8 / ntn;
+            nt = xcd % ntn;
+            mt = idx * g + xcd / ntn;
+        }
+    }
+#endif
     const int tx0 = mt % tiles_x, ty0 = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
     const int y0 = ty0 * TH, x0 = tx0 * TW;
     const int n0 = nt * 64;
@@ -113,8 +159,11 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.wp, 0, (int)((long)36 * cin * p.npad * 4), 0x00020000);
 
-    // ---- halo staging: item = (halo pixel, 16-byte channel quad of the chunk)
-    int pix[NA], lds_off[NA];
+    // ---- halo staging: item = (halo pixel, 16-byte channel quad of the chunk).  The byte offset of an item inside its source
+    // tensor is kept per thread (out-of-image items: an offset beyond any extent, the bounds check returns 0); the chunk's
+    // channel offset goes into the instruction's scalar offset, so a load is one instruction and no address arithmetic.
+    unsigned pixoff[NA];
+    int lds_off[NA], pixi[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int item = tid + NTHR * i;
@@ -122,25 +171,33 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
         const int hy = hp / HWP, hx = hp - hy * HWP;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
         const bool ok = (hp < HP) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
-        pix[i] = ok ? (b * p.H + yy) * p.W + xx : -1;
+        pixi[i] = ok ? (b * p.H + yy) * p.W + xx : -1;
+        pixoff[i] = ok ? (unsigned)((pixi[i] * p.lda0 + c4 * 4) * 4) : RAFT_OOB;
         lds_off[i] = hp < HP ? hy * RS + hx * 16 + (hx >> 2) * 4 + 2 * c4 : HH * RS;   // floats; second half at + 8
     }
     f32x4 ra[NA];
-    // source of a chunk (channels [0, c0) come from a0, the rest from a1): descriptor, leading dimension and channel base
-    // of the NEXT chunk are set once per chunk by next_source()
+    // source of a chunk (channels [0, c0) come from a0, the rest from a1): descriptor and scalar channel offset of the NEXT
+    // chunk are set once per chunk; at the switch from a0 to a1 the per-thread offsets are re-derived with a1's pixel stride
     __amdgpu_buffer_rsrc_t rsn = rs0;
-    int ldn = p.lda0, chn = (tid & 3) * 4;
+    int soff_n = 0;
+    bool on_first = true;
     auto next_source = [&](int c) {
         const int ch = c * 16;
         const bool first = ch < p.c0, live = c < nch && !(RAFT_WINO4_ABL & 4);
         const float *base = first ? p.a0 : (p.c1 ? p.a1 : p.a0);
         const int ext = first ? (int)((((long)M - 1) * p.lda0 + p.c0) * 4) : (p.c1 ? (int)((((long)M - 1) * p.lda1 + p.c1) * 4) : 0);
         rsn = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? ext : 0, 0x00020000);   // past the last chunk: empty
-        ldn = first ? p.lda0 : p.lda1;
-        chn = (first ? ch : ch - p.c0) + (tid & 3) * 4;
+        soff_n = (first ? ch : ch - p.c0) * 4;
+        if (on_first && !first) {   // wave-uniform, taken once
+            on_first = false;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                pixoff[i] = pixi[i] >= 0 ? (unsigned)((pixi[i] * p.lda1 + (tid & 3) * 4) * 4) : RAFT_OOB;
+        }
     };
-    // branch-free: an out-of-image item has pix = -1, i.e. a byte offset far beyond any extent -> the bounds check returns 0
-    auto gload_item = [&](int i) { ra[i] = raft_buffer_load_f4(rsn, (unsigned)((pix[i] * ldn + chn) * 4)); };
+    auto gload_item = [&](int i) {
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsn, (int)pixoff[i], soff_n, 0));
+    };
     auto lstore_item = [&](int i, int buf) {
         float *dst = smem + buf * A_BUF + lds_off[i];
         *(f32x2 *)dst = f32x2{ra[i][0], ra[i][1]};
@@ -149,100 +206,98 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
 
     // ---- fragments
     const int a_lane = (4 * rb) * RS + 68 * LR + 2 * G;   // floats: patch origin of tile LR in row block rb, quad G
-    auto rd = [&](int buf, int r, int j, int h) -> f32x2 {
-        return *(const f32x2 *)(smem + buf * A_BUF + a_lane + r * RS + 16 * j + 4 * (j >> 2) + 8 * h);
+    auto rd = [&](int buf, int r, int j, int h) -> w4v2 {   // buf, r, j, h are compile-time: one base register + an immediate
+        return *(const w4v2 *)(smem + a_lane + (buf * A_BUF + r * RS + 16 * j + 4 * (j >> 2) + 8 * h));
     };
-    // weights: packed in the order the loop consumes them, [chunk][slot q][k-quad G][n][2] (packing.py pack_conv_winograd4):
-    // the fragment of slot q for lane (G, n) is 8 bytes, the stream advances by one constant stride per slot
-    const unsigned b_lane = (unsigned)(((G * p.npad) + n0 + cbp * 32 + LR) * 8);   // bytes
-    const unsigned qstride = (unsigned)(4 * p.npad) * 8u;                          // bytes per slot
-    unsigned wrow = 0;                                                             // wave-uniform
-    f32x2 fb[NR][2];
+    // weights: packed in the order the loop consumes them, [chunk][slot q][k-quad G][n / 32][n % 16][(n / 16) % 2][2]
+    // (packing.py pack_conv_winograd4): the fragments of slot q for lane (G, n % 16) and BOTH column blocks of the wave are
+    // one 16-byte load, and the stream advances by one constant stride per slot
+    const unsigned b_lane = (unsigned)(((G * (p.npad >> 5) + (n0 >> 5) + cbp) * 16 + LR) * 16);   // bytes
+    const unsigned qstride = (unsigned)(4 * p.npad) * 8u;                                     // bytes per slot
+    unsigned wrow = 0;                                                                        // wave-uniform
+    f32x4 fb[NR];   // [slot] = {cb 0: k 2h, 2h + 1; cb 1: k 2h, 2h + 1}
     auto frag_b = [&](int q) {   // called once per slot, in order: fetches the fragments of slot q (mod 72) of the stream
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            fb[q & (NR - 1)][j] = __builtin_bit_cast(
-                f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsw, (int)(b_lane + j * 128), (int)wrow, 0));
+        fb[q & (NR - 1)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)b_lane, (int)wrow, 0));
         wrow += qstride;
+        asm volatile("" : "+s"(wrow));   // keep it ONE running scalar: hipcc otherwise keeps 72 loop-invariant products in (spilled) SGPRs
     };
 
     // 72 accumulator tiles = 288 registers: the accumulator file holds 256, and hipcc picks ONE register class for every
     // MFMA of a function (with the builtin it keeps all 72 tiles in AGPRs and shuffles the overflow through copies: 1584
-    // v_accvgpr moves per K chunk and scratch spills).  So the MFMAs are inline asm: taps 0..31 accumulate in AGPRs ("+a"),
-    // taps 32..35 in VGPRs ("+v").  hipcc pads no hazards of an asm statement (cdna_hip_programming.md 5.7): the two wait
-    // states between a VALU write of an operand and the MFMA are inside the string, the MFMA -> VALU read distance of the
-    // epilogue is the nop statement after the loop; accumulate chains (D = C) need none.
-    // tile index = tap * 2 + column block; tiles 0..W4_ATILES-1 in AGPRs, the rest in VGPRs (a few AGPRs are left to the
-    // register allocator: with all 256 taken it spills accumulators to scratch around the epilogue)
-#define X(i) f32x4 acc_##i = f32x4{0.f, 0.f, 0.f, 0.f};
-    W4_TILES(X)
+    // v_accvgpr moves per K chunk and scratch spills).  So the MFMAs are inline asm: most tiles accumulate in AGPRs ("+a"),
+    // the last ones in VGPRs ("+v").  hipcc pads no hazards of an asm statement (cdna_hip_programming.md 5.7): the two wait
+    // states between a VALU write of an operand and the MFMA are inside the string of the FIRST MFMA of a slot (the
+    // operands of a slot are computed in the slot before), the MFMA -> VALU read distance of the epilogue is the nop
+    // statement after the loop; accumulate chains (D = C) need none.
+    // taps 0..W4_ATAPS-1 in AGPRs, the rest in VGPRs (a few AGPRs are left to the register allocator: with all 256 taken it
+    // spills accumulators to scratch around the epilogue)
+#define X(t) f32x4 accA_##t = f32x4{0.f, 0.f, 0.f, 0.f}, accB_##t = f32x4{0.f, 0.f, 0.f, 0.f};
+    W4_TAPS(X)
 #undef X
     int acc_end_ = 0;   // closes the explicit capture lists (implicit capture does not reach into discarded if-constexpr branches)
-#define X(i) &acc_##i,
-    auto mma = [W4_TILES(X) & acc_end_](auto tile, float a, float bw) {
+    // the four MFMAs of a tap slot (k-steps 2h, 2h + 1 x the wave's two column blocks) are ONE asm statement on the tap's two
+    // accumulator tiles: hipcc pads every asm boundary that a VALU instruction follows
+#define X(t) &accA_##t, &accB_##t,
+    auto mma4 = [W4_TAPS(X) & acc_end_](auto tap, float a0, float a1, f32x4 bw) {
 #undef X
-        constexpr int IDX = decltype(tile)::value;
-#define X(i)                                                                                                        \
-    if constexpr (IDX == i) {                                                                                      \
-        if constexpr (i < W4_ATILES)                                                                                    \
-            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc_##i) : "v"(a), "v"(bw));    \
-        else                                                                                                       \
-            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc_##i) : "v"(a), "v"(bw));    \
+        constexpr int T = decltype(tap)::value;
+#define X(t)                                                                                                                 \
+    if constexpr (T == t) {                                                                                                 \
+        if constexpr (t < W4_ATAPS)                                                                                         \
+            asm volatile(W4_MFMA4 : "+a"(accA_##t), "+a"(accB_##t) : "v"(a0), "v"(a1), "v"(bw[0]), "v"(bw[1]), "v"(bw[2]), "v"(bw[3])); \
+        else                                                                                                                \
+            asm volatile(W4_MFMA4 : "+v"(accA_##t), "+v"(accB_##t) : "v"(a0), "v"(a1), "v"(bw[0]), "v"(bw[1]), "v"(bw[2]), "v"(bw[3])); \
     }
-        W4_TILES(X)
+        W4_TAPS(X)
 #undef X
     };
-#define X(i) &acc_##i,
-    auto acc_of = [W4_TILES(X) & acc_end_](auto tile) -> f32x4 {
+#define X(t) &accA_##t, &accB_##t,
+    auto acc_of = [W4_TAPS(X) & acc_end_](auto tile) -> f32x4 {   // tile = tap * 2 + column block
 #undef X
         constexpr int IDX = decltype(tile)::value;
-#define X(i) if constexpr (IDX == i) return acc_##i;
-        W4_TILES(X)
+#define X(t)                                       \
+    if constexpr (IDX == 2 * t) return accA_##t;   \
+    if constexpr (IDX == 2 * t + 1) return accB_##t;
+        W4_TAPS(X)
 #undef X
     };
 
-    // ---- stage 1 of one phase, column j: raw[] = the patch rows the phase needs, Wn[row][j] = B^T rows of the phase
-    f32x2 W[2][2][6];     // [instance parity][row in phase][patch column]
-    f32x2 raw[6];
-    auto s1_read = [&](int buf, int ph, int j, int h) {
-        if (RAFT_WINO4_ABL & 2) return;
-        if (ph < 2) {
-#pragma unroll
-            for (int r = 1; r <= 4; ++r) raw[r] = rd(buf, r, j, h);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) raw[r] = rd(buf, r, j, h);
-        }
-    };
-    auto s1_calc = [&](int par, int ph, int j) {
+    // ---- stage 1 (B^T over the patch rows).  R[r - 1][j] = patch rows 1..4 of the current half (every phase needs them: read
+    // once); rows 0 and 5 are read when phase C's rows are formed.  W[parity][row in phase][patch column].
+    w4v2 R[4][6], W[2][2][6], e0, e5;
+    auto s1_pair = [&](int par, int ph, int j) {   // phases A (+-a) and B (+-b) from R
         if (RAFT_WINO4_ABL & 2) {
-            W[par][0][j] = W[par][1][j] = f32x2{1.f, 1.f};
+            W[par][0][j] = W[par][1][j] = w4v2{1.f, 1.f};
             return;
         }
-        if (ph == 0) {
-            const f32x2 t1 = raw[4] - B2 * raw[2], t2 = raw[3] - B2 * raw[1];
-            W[par][0][j] = t1 + PA * t2;
-            W[par][1][j] = t1 - PA * t2;
-        } else if (ph == 1) {
-            const f32x2 t1 = raw[4] - A2 * raw[2], t2 = raw[3] - A2 * raw[1];
-            W[par][0][j] = t1 + PB * t2;
-            W[par][1][j] = t1 - PB * t2;
-        } else {
-            W[par][0][j] = (raw[4] - SS * raw[2]) + PP * raw[0];
-            W[par][1][j] = (raw[5] - SS * raw[3]) + PP * raw[1];
+        const float c2 = ph == 0 ? B2 : A2, c1 = ph == 0 ? PA : PB;
+        const w4v2 t1 = R[3][j] - c2 * R[1][j], t2 = R[2][j] - c2 * R[0][j];
+        W[par][0][j] = t1 + c1 * t2;
+        W[par][1][j] = t1 - c1 * t2;
+    };
+    auto s1_edge = [&](int par, int j) {           // phase C (0, inf) from R and the freshly read rows 0 / 5
+        if (RAFT_WINO4_ABL & 2) {
+            W[par][0][j] = W[par][1][j] = w4v2{1.f, 1.f};
+            return;
         }
+        W[par][0][j] = (R[3][j] - SS * R[1][j]) + PP * e0;
+        W[par][1][j] = (e5 - SS * R[2][j]) + PP * R[0][j];
     };
     // ---- stage 2: V[tx] of a row from its W[0..5]; computed one tap ahead (pairs together)
-    f32x2 V[6];
-    auto s2_calc = [&](const f32x2 *wr, int tx) {   // fills V[tx] (and V[tx + 1] for the first tap of a pair)
+    w4v2 V[6];
+    auto s2_calc = [&](const w4v2 *wr, int tx) {   // fills V[tx] (and V[tx + 1] for the first tap of a pair)
+        if (RAFT_WINO4_ABL & 16) {
+            V[tx] = wr[tx];
+            return;
+        }
         if (tx == 0) {
             V[0] = (wr[4] - SS * wr[2]) + PP * wr[0];
         } else if (tx == 1) {
-            const f32x2 t1 = wr[4] - B2 * wr[2], t2 = wr[3] - B2 * wr[1];
+            const w4v2 t1 = wr[4] - B2 * wr[2], t2 = wr[3] - B2 * wr[1];
             V[1] = t1 + PA * t2;
             V[2] = t1 - PA * t2;
         } else if (tx == 3) {
-            const f32x2 t1 = wr[4] - A2 * wr[2], t2 = wr[3] - A2 * wr[1];
+            const w4v2 t1 = wr[4] - A2 * wr[2], t2 = wr[3] - A2 * wr[1];
             V[3] = t1 + PB * t2;
             V[4] = t1 - PB * t2;
         } else if (tx == 5) {
@@ -250,7 +305,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
         }
     };
 
-    // ---- prologue: chunk 0 into buffer 0, stage 1 of (chunk 0, half 0, phase 0), the first PF weight fragments, V[0]
+    // ---- prologue: chunk 0 into buffer 0, rows 1..4 + stage 1 of (chunk 0, half 0, phase A), the first PF weight fragments
     next_source(0);
 #pragma unroll
     for (int i = 0; i < NA; ++i) gload_item(i);
@@ -261,57 +316,70 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     raft_barrier_lds();
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        s1_read(0, 0, j, 0);
-        s1_calc(0, 0, j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R[r][j] = (RAFT_WINO4_ABL & 2) ? w4v2{1.f, 1.f} : rd(0, r + 1, j, 0);
+        s1_pair(0, 0, j);
     }
     s2_calc(W[0][0], 0);
 
-    for (int c = 0; c < nch; ++c) {
-        const int buf = c & 1;
+    // one 16-channel chunk; BUF = its LDS buffer (compile-time: every LDS access is base register + immediate)
+    auto chunk = [&](auto buf_c, int c) {
+        constexpr int BUF = decltype(buf_c)::value;
         next_source(c + 1);
         w4_static_for<6>([&](auto inst_c) {
             constexpr int inst = decltype(inst_c)::value;
-            constexpr int ph = inst % 3, par = inst & 1;
-            // the instance whose stage 1 runs under this one's MFMAs
-            constexpr int n_inst = (inst + 1) % 6, n_h = n_inst / 3, n_ph = n_inst % 3;
-            const int n_buf = inst == 5 ? buf ^ 1 : buf;
+            constexpr int h = inst / 3, ph = inst % 3, par = inst & 1;
+            // under this instance's MFMAs: phase A -> rows (+-b) of the same half from R; phase B -> rows 0 / 5 are read and
+            // rows (0, inf) formed; phase C -> R is dead: rows 1..4 of the NEXT half are read and its rows (+-a) formed
+            constexpr int n_h = ph == 2 ? 1 - h : h;
+            constexpr int n_buf = (ph == 2 && h == 1) ? 1 - BUF : BUF;
             if (inst == 5) raft_barrier_lds();   // chunk c + 1 is in the other buffer; every read of this one has been consumed
             w4_static_for<12>([&](auto u_c) {
                 constexpr int u = decltype(u_c)::value;
-                constexpr int row = u / 6, tx = u % 6;
+                constexpr int row = u / 6, tx = u % 6, j = u >> 1;
                 constexpr int q = inst * 12 + u;
                 constexpr int t = tap_row(ph, row) * 6 + tx;
-                // quarter 0: weight fragments PF slots ahead
-                if (!(RAFT_WINO4_ABL & 1)) frag_b((q + PF) % 72);   // runs into the next chunk (past the last one: out of range, 0)
-                mma(std::integral_constant<int, 2 * t>{}, V[tx][0], fb[q & (NR - 1)][0][0]);
-                __builtin_amdgcn_sched_barrier(0);
-                // quarter 1: stage 1 of the next instance -- LDS reads of column u / 2 in even slots, arithmetic in odd ones
-                // (unconditional: under the last chunk's last phase it transforms stale data that nobody uses -- a branch here
-                // lets the compiler sink the reads next to the arithmetic)
-                if ((u & 1) == 0)
-                    s1_read(n_buf, n_ph, u >> 1, n_h);
-                else
-                    s1_calc(par ^ 1, n_ph, u >> 1);
-                mma(std::integral_constant<int, 2 * t + 1>{}, V[tx][0], fb[q & (NR - 1)][1][0]);
-                __builtin_amdgcn_sched_barrier(0);
-                // quarter 2: stage 2 one tap ahead (the next row after the last tap of a row)
-                if constexpr (u < 11) s2_calc(W[par][(u + 1) / 6], (u + 1) % 6);
-                mma(std::integral_constant<int, 2 * t>{}, V[tx][1], fb[q & (NR - 1)][0][1]);
-                __builtin_amdgcn_sched_barrier(0);
-                // quarter 3: the next chunk's halo tile, one item per slot
+                // weight fragments PF slots ahead (runs into the next chunk; past the last one: out of range, 0)
+                if (!(RAFT_WINO4_ABL & 1)) frag_b((q + PF) % 72);
+                // stage 1 of the next instance (unconditional: under the last chunk's last phase it transforms stale data that
+                // nobody uses -- a branch here lets the compiler sink the reads next to the arithmetic)
+                if (!(RAFT_WINO4_ABL & 2)) {
+                    if constexpr (ph == 1 && (u & 1) == 0) {
+                        e0 = rd(BUF, 0, j, h);
+                        e5 = rd(BUF, 5, j, h);
+                    }
+                    if constexpr (ph == 2 && (u & 1) == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) R[r][j] = rd(n_buf, r + 1, j, n_h);
+                    }
+                }
+                if constexpr ((u & 1) == 1) {
+                    if constexpr (ph == 0) s1_pair(par ^ 1, 1, j);
+                    if constexpr (ph == 1) s1_edge(par ^ 1, j);
+                    if constexpr (ph == 2) s1_pair(par ^ 1, 0, j);
+                }
+                // the next chunk's halo tile, one item per slot
                 {
                     constexpr int li = q - LOAD_SLOT0, si = q - LOAD_SLOT0 - STORE_LAG;
-                    if (li >= 0 && li < NA) gload_item(li);
-                    if (si >= 0 && si < NA) lstore_item(si, buf ^ 1);
+                    if constexpr (li >= 0 && li < NA) gload_item(li);
+                    if constexpr (si >= 0 && si < NA) lstore_item(si, 1 - BUF);
                 }
-                mma(std::integral_constant<int, 2 * t + 1>{}, V[tx][1], fb[q & (NR - 1)][1][1]);
-                if (u == 11) {
-                    // V[0] of the next instance's first row: its W is complete now (column 5 was finished in this slot)
-                    s2_calc(W[par ^ 1][0], 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                W4_SB();
+                mma4(std::integral_constant<int, t>{}, V[tx][0], V[tx][1], fb[q & (NR - 1)]);
+                W4_SB();
+                // stage 2 one tap ahead (the next row after the last tap of a row; after the last tap of an instance V[0] of the
+                // next instance's first row, whose W was completed in this slot)
+                if constexpr (u < 11) s2_calc(W[par][(u + 1) / 6], (u + 1) % 6);
+                if constexpr (u == 11) s2_calc(W[par ^ 1][0], 0);
             });
         });
+    };
+    // two chunks per trip (one per LDS buffer).  An odd chunk count runs one ghost chunk: its halo tile was fetched through an
+    // empty descriptor (zeros) and its weights lie beyond the stream (zeros), so it adds nothing -- a branch around it would put
+    // 72 accumulator tiles through phi copies
+    for (int c = 0; c < nch; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        chunk(std::integral_constant<int, 1>{}, c + 1);
     }
 
     // the last MFMAs' results must have left the matrix pipe before a VALU reads them (8-pass MFMA: 12 wait states)
@@ -414,5 +482,5 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
 #pragma clang diagnostic pop
 
 // launcher (conv_wino4.hip); `a.wp` holds the F(4x4, 3x3)-transformed weights in consumption order
-// (Cin/16, 72, 4, npad, 2) -- tf_raft_amd/packing.py pack_conv_winograd4.  epi: EPI_LINEAR / EPI_RELU / EPI_RES.
+// (Cin/16, 72, 4, npad/32, 16, 2, 2) -- tf_raft_amd/packing.py pack_conv_winograd4.  epi: EPI_LINEAR / EPI_RELU / EPI_RES.
 int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s);

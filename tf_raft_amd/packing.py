@@ -149,8 +149,9 @@ def wino4_tap_of_slot(q: int):
 def pack_conv_winograd4(kernel: np.ndarray, bias: np.ndarray,
                         sources: Sequence[Tuple[int, int]] = None) -> Tuple[np.ndarray, np.ndarray, int]:
     """F(4x4, 3x3)-transformed kernel in the order ``conv_wino4_kernel`` (csrc/conv_wino4.h) consumes it:
-    wp float32[Kpad/16, 72, 4, npad, 2] = [16-channel chunk][slot q][k-quad G][n][e] holding
-    U[tap(q)][16 c + 4 G + 2 h(q) + e][n] -- a wave's weight stream is one constant stride per slot.
+    wp float32[Kpad/16, 72, 4, npad/32, 16, 2, 2] = [16-channel chunk][slot q][k-quad G][n / 32][n % 16][(n / 16) % 2][e]
+    holding U[tap(q)][16 c + 4 G + 2 h(q) + e][n] -- a lane's fragments of a slot for both column blocks of its wave are one
+    16-byte load and a wave's weight stream is one constant stride per slot.
     ``sources`` as in ``pack_conv`` (padded channel counts: multiples of 16).  Returns (wp, bias[npad], npad)."""
     u = winograd4_kernel(kernel)
     _, _, cin, cout = u.shape
@@ -170,11 +171,11 @@ def pack_conv_winograd4(kernel: np.ndarray, bias: np.ndarray,
         k_src += c
         k_dst += cp
     nch = kpad // 16
-    wp = np.zeros((nch, 72, 4, npad, 2), dtype=np.float32)
+    wp = np.zeros((nch, 72, 4, npad // 32, 16, 2, 2), dtype=np.float32)
     for q in range(72):
         ty, tx, h = wino4_tap_of_slot(q)
-        blk = full[ty, tx].reshape(nch, 4, 4, npad)                       # [chunk][G][channel in quad][n]
-        wp[:, q] = blk[:, :, 2 * h:2 * h + 2, :].transpose(0, 1, 3, 2)    # [chunk][G][n][e]
+        blk = full[ty, tx].reshape(nch, 4, 4, npad // 32, 2, 16)          # [chunk][G][channel in quad][n / 32][(n / 16) % 2][n % 16]
+        wp[:, q] = blk[:, :, 2 * h:2 * h + 2].transpose(0, 1, 3, 5, 4, 2)  # [chunk][G][n / 32][n % 16][(n / 16) % 2][e]
     b = np.zeros((npad,), dtype=np.float32)
     b[:cout] = np.asarray(bias, dtype=np.float32)
     return wp, b, npad
