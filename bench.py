@@ -494,12 +494,49 @@ def main():
         two_us = float(stage_ms['corr_lookup'] + stage_ms['convc1']) * 1e3
         inc_us = max(fused_us - stage_ms['convc1'] * 1e3, 1e-3)
         lk = result['roofline_corr_lookup']
-        lk['in_product_loop'] = {
+        # NOT a kernel duration: a difference between two different kernels' times (fused kernel - stand-alone convc1).  Kept
+        # as what it is -- an estimate of what the lookup adds inside the fused kernel -- and never quoted as a roofline fraction
+        lk['in_product_loop_model'] = {
             'kernel': 'lookup fused into convc1 (raft_lookup_convc1_f32)', 'fused_us_per_launch': round(fused_us, 2),
             'two_kernels_us_per_launch': round(two_us, 2), 'standalone_convc1_us': round(stage_ms['convc1'] * 1e3, 2),
-            'incremental_lookup_us': round(inc_us, 2),
-            'algorithmic_gbs_on_incremental_time': round(bytes_['corr_lookup'] / (inc_us * 1e-6) / 1e9, 1),
-            'frac_of_measured_copy_on_incremental_time': round(bytes_['corr_lookup'] / (inc_us * 1e-6) / 1e9 / copy_gbs, 4)}
+            'estimated_incremental_lookup_us': round(inc_us, 2),
+            'note': 'fused kernel time minus stand-alone convc1 time: a model, not a measured kernel duration'}
+        # The same stand-alone kernel in the single-stream loop at 8 pairs (BASELINE configs[2] per GPU): a 550 MB volume,
+        # larger than the 256 MiB Infinity Cache, which the 275 MB volume of 4 pairs is not (SURVEY 8d asks for B >= 8).
+        if world == 1 and B != 8:
+            i8a = torch.cat([img1, img1.flip(0)])[:8] if B >= 4 else img1[:1].expand(8, -1, -1, -1).contiguous()
+            i8b = torch.cat([img2, img2.flip(0)])[:8] if B >= 4 else img2[:1].expand(8, -1, -1, -1).contiguous()
+            f1, f2 = model.fnet([2 * (i8a / 255.0) - 1.0, 2 * (i8b / 255.0) - 1.0])
+            cn8 = model.cnet(2 * (i8a / 255.0) - 1.0)
+            corr8 = CorrBlock(f1, f2, num_levels=4, radius=4)
+            st8 = model._get_state(8, h, w, device)
+            up8 = torch.empty((ITERS, 8, H, W, 2), device=device)
+            _ffi.set_option('RAFT_LOOKUP_FUSED', 0)
+            buf = (C.c_float * len(STAGES))()
+            acc8 = np.zeros(len(STAGES))
+            for _ in range(2):
+                model._prepare(cn8, st8)
+                _ffi.check(_dev.lib().raft_iterate_basic_timed_f32(
+                    C.byref(model.update_block.c), _dev.ptr(corr8._pyr), corr8._off, 8, h, w, ITERS, C.byref(st8.c),
+                    _dev.ptr(up8), _dev.stream_ptr(), buf), 'iterate_basic_timed')
+                acc8 += np.array(list(buf))
+            _ffi.set_option('RAFT_LOOKUP_FUSED', None)
+            l8_ms = max(float(acc8[0]) / (2 * ITERS) - bracket_ms, 1e-6)
+            b8 = stage_work(8, h, w)[1]['corr_lookup']
+            tr8, _ = pmc_traffic('corr_lookup', 8)
+            lk['at_8_pairs'] = {'ms_per_launch': round(l8_ms, 5), 'ms_per_launch_between_events': round(float(acc8[0]) / (2 * ITERS), 5),
+                                'bytes_per_launch': b8, 'achieved': round(b8 / (l8_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
+                                'frac': round(b8 / (l8_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                'frac_of_measured_copy': round(b8 / (l8_ms * 1e-3) / 1e9 / copy_gbs, 4), 'traffic': tr8}
+            del i8a, i8b, f1, f2, cn8, corr8, st8, up8
+        best = max(lk['frac_of_measured_copy'], lk.get('at_8_pairs', {}).get('frac_of_measured_copy', 0.0))
+        lk['target'] = {
+            'north_star': '>= 0.60 of the measured HBM copy rate on algorithmic bytes, by kernel duration', 'best_frac_of_measured_copy': best,
+            'target_met': bool(best >= 0.60),
+            'floor': 'PMC traffic is 1.32x the algorithmic bytes (a 10x10 footprint touches 6.9 128-byte tiles of a 4x8-tiled map, '
+                     '3.1 tiles of useful floats): at the copy rate the moved bytes alone are 0.76 of the time budget of the target, an '
+                     'empty launch of this grid 2.5 us more -- at 4 pairs floor 11.4 us against a target of 11.2 us (DESIGN.md section 5); '
+                     'in the product loop the kernel runs fused into convc1 and does not write its 18.6 MB output'}
         # corr_build = pooled-fmap2 pyramid (2 small launches) + ONE fp32-MFMA NT GEMM fmap1 . pyramid^T whose epilogue
         # writes all 4 levels.  Its floor is the GEMM (real FLOPs: every stored correlation value is a C-long dot
         # product), the HBM write of the volume sits below it -- both are reported, bound = "mfma".
