@@ -33,6 +33,10 @@ CASES = [('raft', 64, 96, 12, 0, 'default'), ('raft', 128, 160, 12, 1, 'default'
 CASES += [('raft', 448, 512, 24, s, 'conditioned') for s in (0, 1, 2)]
 CASES += [('small', 448, 512, 24, s, 'conditioned') for s in (0, 1, 2)]
 CASES += [('small', 256, 256, 4, 0, 'conditioned'), ('raft', 1024, 1024, 3, 0, 'conditioned')]
+# round 3: the mid regime (multi-pixel flow: integer-crossing taps, clamped borders, coarse levels) ...
+CASES += [('raft', 448, 512, 24, s, 'mid') for s in (0, 1, 2, 3, 4)] + [('small', 448, 512, 24, s, 'mid') for s in (0, 1)]
+# ... and every element of the batch that test_north_star_benchmarked_batches runs (seed 3, B = 8), each alone
+BATCH_CASES = [('raft', 448, 512, 24, 3, 'conditioned', 8)]
 
 
 def case_key(variant, H, W, iters, seed, regime):
@@ -45,13 +49,14 @@ def case_inputs(variant, H, W, seed, regime, B=1):
     i1 = rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32)
     i2 = rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32)
     wts = wm.init_weights(variant, seed=seed)
-    if regime == 'conditioned':
-        wts = wm.condition_weights(variant, wts)
+    if regime != 'default':
+        wts = wm.condition_weights(variant, wts, regime)
     return i1, i2, wts
 
 
-def run(variant, H, W, iters, seed, regime):
-    i1, i2, wts = case_inputs(variant, H, W, seed, regime)
+def run(variant, H, W, iters, seed, regime, B=1, element=0):
+    i1, i2, wts = case_inputs(variant, H, W, seed, regime, B=B)
+    i1, i2 = i1[element:element + 1], i2[element:element + 1]
     cls = oracle.RAFT if variant == 'raft' else oracle.SmallRAFT
     o32 = cls(wts, iters_pred=iters)([i1, i2])
     o64 = cls(wts, iters_pred=iters, dtype=torch.float64)([i1, i2])
@@ -73,4 +78,13 @@ if __name__ == '__main__':
         print(key, ' '.join(f'{e:.1e}' for e in out[key]['epe32v64']), flush=True)
         with open(path, 'w') as f:
             json.dump(out, f, indent=1)
+    for variant, H, W, iters, seed, regime, B in BATCH_CASES:
+        for b in range(B):
+            key = case_key(variant, H, W, iters, seed, regime) + f'_batch{B}_element{b}'
+            if key in out:
+                continue
+            out[key] = run(variant, H, W, iters, seed, regime, B=B, element=b)
+            print(key, ' '.join(f'{e:.1e}' for e in out[key]['epe32v64']), flush=True)
+            with open(path, 'w') as f:
+                json.dump(out, f, indent=1)
     print('wrote', path)

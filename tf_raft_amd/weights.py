@@ -178,11 +178,22 @@ def init_weights(variant: str, seed: int = 0, perturb: bool = False) -> 'Ordered
 # (x, x + 1) for the whole loop (flow in ~[0.1, 0.9] px after 24 iterations), so no tap can flip and the 1e-3 bound of
 # BASELINE.json's north_star is testable on flow_predictions[-1] itself.  Every other layer keeps its default weights.
 CONDITIONED_HEAD = {'raft': (0.01, (0.02, 0.018)), 'small': (0.005, (0.02, 0.018))}
+# Mid regime (round 3): the same construction with a flow head that is 20x stronger and drifts (+0.2, -0.15) feature pixels per
+# iteration -- after 24 iterations the low-resolution flow spans about [0, 9] x [-10, 2] px with a standard deviation of ~1 px, so
+# lookup taps cross integers at every pyramid level, windows slide over the clamped borders and the coarse levels are sampled
+# away from the identity.  The recurrence is then only MOSTLY well conditioned: in about one run out of three a tap passes
+# within rounding distance of a clamp boundary and the oracle in fp32 and in fp64 part ways on a few percent of the pixels
+# (tests/golden/conditioning.json records which seeds and when), so the tests built on it assert the 1e-3 bound up to such a
+# flip and require the flip to be local (tests/test_gpu_model.py::test_mid_regime_free_running).
+MID_HEAD = {'raft': (0.2, (0.2, -0.15)), 'small': (0.1, (0.2, -0.15))}
 
 
-def condition_weights(variant: str, weights: Dict[str, np.ndarray]) -> 'OrderedDict[str, np.ndarray]':
-    """Copy of ``weights`` with ``update_block/flow_head/conv2`` scaled / biased per ``CONDITIONED_HEAD``."""
-    scale, bias = CONDITIONED_HEAD[variant]
+def condition_weights(variant: str, weights: Dict[str, np.ndarray], regime: str = 'conditioned') -> 'OrderedDict[str, np.ndarray]':
+    """Copy of ``weights`` with ``update_block/flow_head/conv2`` scaled / biased per ``CONDITIONED_HEAD`` (regime
+    'conditioned') or ``MID_HEAD`` (regime 'mid')."""
+    if regime not in ('conditioned', 'mid'):
+        raise ValueError(f"regime must be 'conditioned' or 'mid', got {regime!r}")
+    scale, bias = (CONDITIONED_HEAD if regime == 'conditioned' else MID_HEAD)[variant]
     w = OrderedDict(weights)
     k = 'update_block/flow_head/conv2/'
     w[k + 'kernel'] = (weights[k + 'kernel'] * np.float32(scale)).astype(np.float32)
