@@ -393,8 +393,9 @@ def test_conv2d_winograd_matches_oracle(rng, shape, variant, raft_opt):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize('ks', [1, 2])                      # 8 x 64-pixel workgroups / 4 x 64-pixel workgroups with K split in two
 @pytest.mark.parametrize('shape', [(2, 9, 13), (1, 8, 64), (1, 5, 70), (2, 16, 128), (1, 56, 64)])   # ragged, exact, 2 x-tiles + tail, big
-def test_conv2d_winograd4_matches_oracle(rng, shape):
+def test_conv2d_winograd4_matches_oracle(rng, shape, ks, raft_opt):
     """Winograd F(4x4, 3x3) kernel (conv_wino4.h) against the float64 direct convolution; two sources (the first one
     padded 40 -> 48 channels), N tail 150 -> 192.  Its fp32 deviation is ~3x that of the F(2x2, 3x3) kernel (reported
     next to it and to the direct kernel): bound 6e-5 on outputs of magnitude ~10 where the other kernels have 2e-5."""
@@ -403,20 +404,22 @@ def test_conv2d_winograd4_matches_oracle(rng, shape):
     from tf_raft_amd._ffi import check
     B, H, W = shape
     c_a, c_b, cout = 40, 64, 150
+    raft_opt.set('RAFT_WINO4_KS', str(ks))
+    pad_a = 48 if ks == 1 else 64                # the K split pairs up the 16-channel chunks of each source: multiples of 32
     xa = rng.normal(size=(B, H, W, c_a)).astype(np.float32)
     xb = rng.normal(size=(B, H, W, c_b)).astype(np.float32)
     kernel = (rng.normal(size=(3, 3, c_a + c_b, cout)) * 0.1).astype(np.float32)
     bias = rng.normal(size=(cout,)).astype(np.float32)
     srcs = []
-    for arr, cpad in ((xa, 48), (xb, 64)):
+    for arr, cpad in ((xa, pad_a), (xb, 64)):
         buf = np.zeros((B, H, W, cpad), np.float32)
         buf[..., :arr.shape[-1]] = arr
         srcs.append(_dev.to_device(buf))
-    wp, b, npad = packing.pack_conv_winograd4(kernel, bias, [(c_a, 48), (c_b, 64)])
-    assert wp.shape == (7, 72, 4, npad // 32, 16, 2, 2) and npad == 192
+    wp, b, npad = packing.pack_conv_winograd4(kernel, bias, [(c_a, pad_a), (c_b, 64)])
+    assert wp.shape == ((pad_a + 64) // 16, 72, 4, npad // 32, 16, 2, 2) and npad == 192
     wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
     out = torch.full((B, H, W, cout), float('nan'), device=srcs[0].device)
-    check(_dev.lib().raft_conv2d_winograd4_f32(_dev.ptr(srcs[0]), 48, 48, _dev.ptr(srcs[1]), 64, 64, _dev.ptr(wp_d),
+    check(_dev.lib().raft_conv2d_winograd4_f32(_dev.ptr(srcs[0]), pad_a, pad_a, _dev.ptr(srcs[1]), 64, 64, _dev.ptr(wp_d),
                                                _dev.ptr(b_d), B, H, W, npad, cout, 1, 0.5, _dev.ptr(out), cout,
                                                _dev.stream_ptr()), 'conv2d_winograd4')
     torch.cuda.synchronize()
@@ -425,7 +428,7 @@ def test_conv2d_winograd4_matches_oracle(rng, shape):
     want = 0.5 * torch.relu(tf_ops.conv2d(x.double(), _t(kernel).double(), _t(bias).double())).numpy()
     direct = _conv_device([(xa, 64), (xb, 64)], kernel, bias, act=1, scale=0.5)
     err, err_direct = float(np.abs(got - want).max()), float(np.abs(direct - want).max())
-    report(f'conv2d winograd F(4x4,3x3) {shape}', max_abs_vs_f64=err, direct_vs_f64=err_direct,
+    report(f'conv2d winograd F(4x4,3x3) {shape} ks {ks}', max_abs_vs_f64=err, direct_vs_f64=err_direct,
            rms_vs_f64=float(np.sqrt(((got - want) ** 2).mean())), rms_direct=float(np.sqrt(((direct - want) ** 2).mean())))
     assert not np.isnan(got).any()
     if err >= 6e-5:   # locate a structural fault from one run: worst pixel / channel and the error pattern over tile positions

@@ -261,11 +261,11 @@ static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weig
 // B = 4).  Read per call so that tests can switch it.
 constexpr int RAFT_WINO_DEFAULT = 13;
 constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr, 4: gru_q, 8: fh1}, switch RAFT_SMALL_WINO
-// F(4x4, 3x3) (conv_wino4.h), switch RAFT_CONV_WINO4 = bit mask {1: convc2, 4: conv, 8: fh1_mask0 / fh1}.  Default: the flow /
-// mask head at every size (N = 512: 224 workgroups of 8 x 64 pixels x 64 channels at B = 4 -- 62 us against 88 for F(2x2,3x3),
-// profiles/r07e_wino4_ablation.txt), convc2 (N = 192) from 8 pairs on, where its 2-row-block x 64-channel workgroups are enough
-// to cover the chip (B = 4: 84 workgroups for 256 CUs, slower than F(2x2,3x3)); conv (N = 128) never by default.
-static int wino4_default_mask(const ConvArgs &a) { return 8 | ((int64_t)a.B * a.H * a.W >= 8 * 3584 ? 1 : 0); }
+// F(4x4, 3x3) (conv_wino4.h), switch RAFT_CONV_WINO4 = bit mask {1: convc2, 4: conv, 8: fh1_mask0 / fh1}.  Default (us alone,
+// F(4x4) against F(2x2), profiles/r07i_wino4_bench.txt): the flow / mask head (63 vs 91 at 4 pairs, 128 vs 169 at 8) and convc2
+// (61 vs 76 with the K-split workgroups, 107 vs 132) at every size; conv (N = 128) from 8 pairs on (65 vs 114; at 4 pairs its
+// 112 K-split workgroups lose to F(2x2): 59 vs 49).
+static int wino4_default_mask(const ConvArgs &a) { return 8 | 1 | ((int64_t)a.B * a.H * a.W >= 8 * 3584 ? 4 : 0); }
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
                           hipStream_t s, bool small = false, const raft_conv_weights *wino44 = nullptr) {
     const int mask = small ? raft_opt(RAFT_OPT_SMALL_WINO, RAFT_SMALL_WINO_DEFAULT) : raft_opt(RAFT_OPT_CONV_WINO, RAFT_WINO_DEFAULT);

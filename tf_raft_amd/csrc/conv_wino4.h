@@ -94,11 +94,9 @@ __device__ __forceinline__ void w4_static_for(F &&f) {
 namespace wino4 {
 constexpr float PA = 0.625f, PB = 1.5f;
 constexpr float A2 = PA * PA, B2 = PB * PB, SS = A2 + B2, PP = A2 * B2, A3 = A2 * PA, B3 = B2 * PB;
-constexpr int TW = 64, TH = 8, HH = TH + 2, HWP = TW + 2, HP = HH * HWP;   // 10 x 66 halo pixels
+constexpr int TW = 64, HWP = TW + 2;            // 16 tiles of 4 columns; halo row of 66 pixels
 constexpr int RS = 1124;                       // floats per halo row: 66 * 16 + 17 * 4
-constexpr int A_BUF = HH * RS + 16;            // + one dummy pixel for the padding items of the staging loop
 constexpr int NTHR = 256;
-constexpr int NA = (HP * 4 + NTHR - 1) / NTHR; // 16-byte items per thread per chunk (11)
 constexpr int PF = RAFT_WINO4_PF, NR = 8;
 constexpr int W4_ATAPS = RAFT_WINO4_ATAPS;
 #ifndef RAFT_WINO4_LAG
@@ -106,22 +104,31 @@ constexpr int W4_ATAPS = RAFT_WINO4_ATAPS;
 #endif
 constexpr int LOAD_SLOT0 = 0, STORE_LAG = RAFT_WINO4_LAG;   // halo item i: global load in slot LOAD_SLOT0 + i, LDS write STORE_LAG later
 static_assert(PF >= 1 && PF < NR, "prefetch distance must fit the fragment ring");
-static_assert(LOAD_SLOT0 + NA - 1 + STORE_LAG < 60, "halo writes must precede the chunk's barrier (slot 60)");
 // tap row of (phase, row-in-phase)
 __device__ __forceinline__ constexpr int tap_row(int ph, int row) { return ph == 0 ? 1 + row : (ph == 1 ? 3 + row : 5 * row); }
 }   // namespace wino4
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wunused-lambda-capture"
-template <int EPI>
+// KS = 1: workgroup = 2 row blocks (8 x 64 pixels) x 64 channels, wave = (row block, pair of column blocks).
+// KS = 2: workgroup = 1 row block (4 x 64 pixels) x 64 channels, wave = (pair of column blocks, K half): wave set ks walks the
+// 16-channel chunks ks, ks + 2, ... (a stage = two chunks, staged side by side) and the two partial results meet in LDS after the
+// output transform -- for layers whose 2-row-block workgroups are too few to cover the chip (N <= 256 at 4 pairs).
+template <int EPI, int KS = 1>
 __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     using namespace wino4;
     static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES, "winograd F(4x4) kernel: linear / relu / residual epilogues");
-    __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF];
+    static_assert(KS == 1 || KS == 2, "K split: 1 or 2");
+    constexpr int TH = KS == 1 ? 8 : 4, HH = TH + 2, HP = HH * HWP;   // halo rows x 66 pixels
+    constexpr int A_BUF = HH * RS + 16;                               // + one dummy pixel for the padding items of the staging loop
+    constexpr int NA = (HP * 4 * KS + NTHR - 1) / NTHR;               // 16-byte items per thread per stage (11 / 13)
+    static_assert(LOAD_SLOT0 + NA - 1 + STORE_LAG < 60, "halo writes must precede the chunk's barrier (slot 60)");
+    __shared__ __attribute__((aligned(16))) float smem[2 * KS * A_BUF];   // [stage buffer][K half]
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it (and what derives from it) scalar
     const int G = lane >> 4, LR = lane & 15;
-    const int rb = w & 1, cbp = w >> 1;
+    const int rb = KS == 1 ? (w & 1) : 0, cbp = KS == 1 ? (w >> 1) : (w & 1), ks = KS == 1 ? 0 : (w >> 1);
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int ntn = p.npad / 64;
     const int M = p.B * p.H * p.W;
@@ -152,7 +159,8 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     const int y0 = ty0 * TH, x0 = tx0 * TW;
     const int n0 = nt * 64;
     const int cin = p.c0 + p.c1;
-    const int nch = cin >> 4;
+    const int nch = cin >> 4;        // 16-channel chunks
+    const int nst = nch / KS;        // stages (KS = 2: nch is even and so is c0 / 16 -- the launcher checks)
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.a0, 0, (int)((((long)M - 1) * p.lda0 + p.c0) * 4), 0x00020000);
@@ -167,13 +175,14 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int item = tid + NTHR * i;
-        const int hp = item >> 2, c4 = item & 3;
+        const int hq = item >> 2, c4 = item & 3;
+        const int s2 = hq / HP, hp = hq - s2 * HP;                 // chunk of the stage (KS = 2: 0 / 1), halo pixel
         const int hy = hp / HWP, hx = hp - hy * HWP;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        const bool ok = (hp < HP) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
+        const bool ok = (s2 < KS) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
         pixi[i] = ok ? (b * p.H + yy) * p.W + xx : -1;
-        pixoff[i] = ok ? (unsigned)((pixi[i] * p.lda0 + c4 * 4) * 4) : RAFT_OOB;
-        lds_off[i] = hp < HP ? hy * RS + hx * 16 + (hx >> 2) * 4 + 2 * c4 : HH * RS;   // floats; second half at + 8
+        pixoff[i] = ok ? (unsigned)((pixi[i] * p.lda0 + s2 * 16 + c4 * 4) * 4) : RAFT_OOB;
+        lds_off[i] = s2 < KS ? s2 * A_BUF + hy * RS + hx * 16 + (hx >> 2) * 4 + 2 * c4 : HH * RS;   // floats; second half at + 8
     }
     f32x4 ra[NA];
     // source of a chunk (channels [0, c0) come from a0, the rest from a1): descriptor and scalar channel offset of the NEXT
@@ -181,9 +190,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     __amdgpu_buffer_rsrc_t rsn = rs0;
     int soff_n = 0;
     bool on_first = true;
-    auto next_source = [&](int c) {
-        const int ch = c * 16;
-        const bool first = ch < p.c0, live = c < nch && !(RAFT_WINO4_ABL & 4);
+    auto next_source = [&](int st) {   // st = stage index (KS chunks of 16 channels each, all from one source)
+        const int ch = st * 16 * KS;
+        const bool first = ch < p.c0, live = st < nst && !(RAFT_WINO4_ABL & 4);
         const float *base = first ? p.a0 : (p.c1 ? p.a1 : p.a0);
         const int ext = first ? (int)((((long)M - 1) * p.lda0 + p.c0) * 4) : (p.c1 ? (int)((((long)M - 1) * p.lda1 + p.c1) * 4) : 0);
         rsn = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? ext : 0, 0x00020000);   // past the last chunk: empty
@@ -192,31 +201,34 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
             on_first = false;
 #pragma unroll
             for (int i = 0; i < NA; ++i)
-                pixoff[i] = pixi[i] >= 0 ? (unsigned)((pixi[i] * p.lda1 + (tid & 3) * 4) * 4) : RAFT_OOB;
+                pixoff[i] = pixi[i] >= 0 ? (unsigned)((pixi[i] * p.lda1 + (((tid + NTHR * i) >> 2) / HP) * 16 + (tid & 3) * 4) * 4) : RAFT_OOB;
         }
     };
     auto gload_item = [&](int i) {
         ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsn, (int)pixoff[i], soff_n, 0));
     };
     auto lstore_item = [&](int i, int buf) {
-        float *dst = smem + buf * A_BUF + lds_off[i];
+        float *dst = smem + buf * (KS * A_BUF) + lds_off[i];
         *(f32x2 *)dst = f32x2{ra[i][0], ra[i][1]};
         *(f32x2 *)(dst + 8) = f32x2{ra[i][2], ra[i][3]};
     };
 
     // ---- fragments
-    const int a_lane = (4 * rb) * RS + 68 * LR + 2 * G;   // floats: patch origin of tile LR in row block rb, quad G
+    const int a_lane = ks * A_BUF + (4 * rb) * RS + 68 * LR + 2 * G;   // floats: patch origin of tile LR in row block rb, quad G
     auto rd = [&](int buf, int r, int j, int h) -> w4v2 {   // buf, r, j, h are compile-time: one base register + an immediate
-        return *(const w4v2 *)(smem + a_lane + (buf * A_BUF + r * RS + 16 * j + 4 * (j >> 2) + 8 * h));
+        return *(const w4v2 *)(smem + a_lane + (buf * (KS * A_BUF) + r * RS + 16 * j + 4 * (j >> 2) + 8 * h));
     };
     // weights: packed in the order the loop consumes them, [chunk][slot q][k-quad G][n / 32][n % 16][(n / 16) % 2][2]
     // (packing.py pack_conv_winograd4): the fragments of slot q for lane (G, n % 16) and BOTH column blocks of the wave are
     // one 16-byte load, and the stream advances by one constant stride per slot
     const unsigned b_lane = (unsigned)(((G * (p.npad >> 5) + (n0 >> 5) + cbp) * 16 + LR) * 16);   // bytes
     const unsigned qstride = (unsigned)(4 * p.npad) * 8u;                                     // bytes per slot
-    unsigned wrow = 0;                                                                        // wave-uniform
+    unsigned wrow = (unsigned)ks * 72u * qstride;                                             // wave-uniform: first own chunk
     f32x4 fb[NR];   // [slot] = {cb 0: k 2h, 2h + 1; cb 1: k 2h, 2h + 1}
-    auto frag_b = [&](int q) {   // called once per slot, in order: fetches the fragments of slot q (mod 72) of the stream
+    // called once per slot, in order: fetches the fragments of slot q (mod 72) of the wave's stream; `skip` marks the first slot
+    // of the wave's NEXT chunk (KS = 2: the other K half's chunk lies in between)
+    auto frag_b = [&](int q, bool skip = false) {
+        if (KS == 2 && skip) wrow += 72u * qstride;
         fb[q & (NR - 1)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)b_lane, (int)wrow, 0));
         wrow += qstride;
         asm volatile("" : "+s"(wrow));   // keep it ONE running scalar: hipcc otherwise keeps 72 loop-invariant products in (spilled) SGPRs
@@ -340,7 +352,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
                 constexpr int q = inst * 12 + u;
                 constexpr int t = tap_row(ph, row) * 6 + tx;
                 // weight fragments PF slots ahead (runs into the next chunk; past the last one: out of range, 0)
-                if (!(RAFT_WINO4_ABL & 1)) frag_b((q + PF) % 72);
+                if (!(RAFT_WINO4_ABL & 1)) frag_b((q + PF) % 72, q + PF == 72);
                 // stage 1 of the next instance (unconditional: under the last chunk's last phase it transforms stale data that
                 // nobody uses -- a branch here lets the compiler sink the reads next to the arithmetic)
                 if (!(RAFT_WINO4_ABL & 2)) {
@@ -377,9 +389,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     // two chunks per trip (one per LDS buffer).  An odd chunk count runs one ghost chunk: its halo tile was fetched through an
     // empty descriptor (zeros) and its weights lie beyond the stream (zeros), so it adds nothing -- a branch around it would put
     // 72 accumulator tiles through phi copies
-    for (int c = 0; c < nch; c += 2) {
-        chunk(std::integral_constant<int, 0>{}, c);
-        chunk(std::integral_constant<int, 1>{}, c + 1);
+    for (int st = 0; st < nst; st += 2) {
+        chunk(std::integral_constant<int, 0>{}, st);
+        chunk(std::integral_constant<int, 1>{}, st + 1);
     }
 
     // the last MFMAs' results must have left the matrix pipe before a VALU reads them (8-pass MFMA: 12 wait states)
@@ -406,33 +418,84 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     asm volatile("" : "+v"(tid_e));
     const int G_e = (tid_e >> 4) & 3, LR_e = tid_e & 15, rb_e = (tid_e >> 6) & 1, cbp_e = tid_e >> 7;
     const int xb = x0 + 16 * G_e;                                // the lane's tiles 4G + r: pixels xb + 4 r + jx
-    unsigned bo[4], be[4];
-    bool rowok[4];
+    const int ks_e = KS == 1 ? 0 : (tid_e >> 7), cb_e = KS == 1 ? cbp_e : ((tid_e >> 6) & 1), w_e = tid_e >> 6;
+    // one output row `yy` (image row) of the lane's four tiles for column block j: bias, activation / residual, stores.
+    // Element (r, jx) = pixel xb + 4 r + jx: wave-uniform byte offset from the lane base; tiles cut by the image border
+    // (`interior` false, wave-uniform) add the per-element out-of-range bit.
+    // lane bases of the (up to four) output rows this wave finishes: KS = 1 rows 4 rb + i, KS = 2 rows 2 ks + i (i < 2)
+    constexpr int NROW = KS == 1 ? 4 : 2;
+    unsigned bo[NROW], be[NROW];
+    bool rowok[NROW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int yy = y0 + 4 * rb_e + i;
+    for (int i = 0; i < NROW; ++i) {
+        const int yy = y0 + (KS == 1 ? 4 * rb_e : 2 * ks_e) + i;
         const unsigned pix0 = (unsigned)((b * p.H + yy) * p.W + xb);
         bo[i] = pix0 * p.ldo0 * 4u;
         be[i] = HAS_E0 ? pix0 * p.lde0 * 4u : 0u;
         rowok[i] = yy < p.H;
     }
-    w4_static_for<2>([&](auto j_c) {
-        constexpr int j = decltype(j_c)::value;
-        const int n = n0 + (cbp_e * 2 + j) * 16 + LR_e;
-        const bool nok = n < p.nvalid;                                      // channel beyond nvalid: every access out of range
-        const float bias = p.bias[n];                                       // bias has npad entries
-        // A^T over the tap rows, one tap column at a time (whole tiles: the four registers of an accumulator are read
-        // together): T[i][tx]
-        f32x4 T[4][6];
+    float bias2[2];
+    unsigned nofs[2];
+    bool nok2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + (cb_e * 2 + j) * 16 + LR_e;
+        nok2[j] = n < p.nvalid;                                            // channel beyond nvalid: every access out of range
+        nofs[j] = (unsigned)n * 4u;
+        bias2[j] = p.bias[n];                                              // bias has npad entries
+    }
+    // rows of two tiles (registers 2 rh, 2 rh + 1 of the accumulators): bias, activation / residual, stores.  Element (r, jx) =
+    // pixel xb + 4 r + jx: wave-uniform byte offset from the lane base; tiles cut by the image border (`interior` false,
+    // wave-uniform) add the per-element out-of-range bit.  i = index into bo / be / rowok (compile-time at every call site).
+    auto emit = [&](int j, int i, int rh, const f32x2 *Y) {
+        const float bias = bias2[j];
+        const unsigned vo = nok2[j] ? bo[i] + nofs[j] : RAFT_OOB, ve = (HAS_E0 && nok2[j]) ? be[i] + nofs[j] : RAFT_OOB;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * rh + rr;
+            float xv[4];
+            if (HAS_E0) {
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    const unsigned dead = (interior | (rowok[i] & (xb + 4 * r + jx < p.W))) ? 0u : RAFT_OOB;
+                    xv[jx] = bload(re0, ve | dead, (4 * r + jx) * p.lde0 * 4);
+                }
+            }
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                float v = Y[jx][rr] + bias;
+                if (EPI == EPI_RES) {
+                    v = fmaxf(xv[jx] + fmaxf(v, 0.f), 0.f);
+                } else {
+                    if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                    v *= p.scale;
+                }
+                if ((RAFT_WINO4_ABL & 8) && v != 12345.678f) continue;
+                const unsigned dead = (interior | (rowok[i] & (xb + 4 * r + jx < p.W))) ? 0u : RAFT_OOB;
+                bstore(v, ro0, vo | dead, (4 * r + jx) * p.ldo0 * 4);
+            }
+        }
+    };
+    // KS = 2: the two K halves of a (row block, column block pair) meet after the (linear) output transform: wave set ks
+    // finishes output rows 2 ks, 2 ks + 1 of every tile and hands the other two rows of its partial result to its partner
+    // (wave w ^ 2) through LDS -- [j][rh][destination wave][row][jx][lane] float2 in the halo buffers (32 KB)
+    f32x2 *xch = (f32x2 *)smem;
+    if (KS == 2) raft_barrier_lds();   // every wave is done reading its last halo tile
+    // one column block j and one PAIR of tiles (accumulator registers 2 rh, 2 rh + 1) at a time: A^T over the tap rows for
+    // each tap column (T[i][tx]), then A over the tap columns -- 48 registers of T instead of 96 for whole accumulators
+    w4_static_for<4>([&](auto jr_c) {
+        constexpr int j = decltype(jr_c)::value >> 1, rh = decltype(jr_c)::value & 1;
+        f32x2 T[4][6], keep[2][4];
         w4_static_for<6>([&](auto tx_c) {
             constexpr int tx = decltype(tx_c)::value;
-            const f32x4 m0 = acc_of(std::integral_constant<int, 2 * tx + j>{}),
-                        m1 = acc_of(std::integral_constant<int, 2 * (6 + tx) + j>{}),
-                        m2 = acc_of(std::integral_constant<int, 2 * (12 + tx) + j>{}),
-                        m3 = acc_of(std::integral_constant<int, 2 * (18 + tx) + j>{}),
-                        m4 = acc_of(std::integral_constant<int, 2 * (24 + tx) + j>{}),
-                        m5 = acc_of(std::integral_constant<int, 2 * (30 + tx) + j>{});
-            const f32x4 sa = m1 + m2, da = m1 - m2, sb = m3 + m4, db = m3 - m4;
+            auto half = [&](f32x4 a) { return f32x2{a[2 * rh], a[2 * rh + 1]}; };
+            const f32x2 m0 = half(acc_of(std::integral_constant<int, 2 * tx + j>{})),
+                        m1 = half(acc_of(std::integral_constant<int, 2 * (6 + tx) + j>{})),
+                        m2 = half(acc_of(std::integral_constant<int, 2 * (12 + tx) + j>{})),
+                        m3 = half(acc_of(std::integral_constant<int, 2 * (18 + tx) + j>{})),
+                        m4 = half(acc_of(std::integral_constant<int, 2 * (24 + tx) + j>{})),
+                        m5 = half(acc_of(std::integral_constant<int, 2 * (30 + tx) + j>{}));
+            const f32x2 sa = m1 + m2, da = m1 - m2, sb = m3 + m4, db = m3 - m4;
             T[0][tx] = m0 + (sa + sb);
             T[1][tx] = PA * da + PB * db;
             T[2][tx] = A2 * sa + B2 * sb;
@@ -441,40 +504,36 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
         });
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x4 sa = T[i][1] + T[i][2], da = T[i][1] - T[i][2], sb = T[i][3] + T[i][4], db = T[i][3] - T[i][4];
-            f32x4 Y[4];
+            const f32x2 sa = T[i][1] + T[i][2], da = T[i][1] - T[i][2], sb = T[i][3] + T[i][4], db = T[i][3] - T[i][4];
+            f32x2 Y[4];
             Y[0] = T[i][0] + (sa + sb);
             Y[1] = PA * da + PB * db;
             Y[2] = A2 * sa + B2 * sb;
             Y[3] = (A3 * da + B3 * db) + T[i][5];
-            // element (r, jx) = pixel xb + 4 r + jx of row y0 + 4 rb + i: wave-uniform byte offset from the lane base; tiles cut
-            // by the image border (`interior` false, wave-uniform) add the per-element out-of-range bit
-            const unsigned vo = nok ? bo[i] + (unsigned)n * 4u : RAFT_OOB, ve = nok ? be[i] + (unsigned)n * 4u : RAFT_OOB;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float xv[4];
-                if (HAS_E0) {
-#pragma unroll
-                    for (int jx = 0; jx < 4; ++jx) {
-                        const unsigned dead = (interior | (rowok[i] & (xb + 4 * r + jx < p.W))) ? 0u : RAFT_OOB;
-                        xv[jx] = bload(re0, ve | dead, (4 * r + jx) * p.lde0 * 4);
-                    }
-                }
+            if (KS == 1) {
+                emit(j, i, rh, Y);
+            } else {
+                const bool mine = (i >> 1) == ks_e;   // wave-uniform
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) {
-                    float v = Y[jx][r] + bias;
-                    if (EPI == EPI_RES) {
-                        v = fmaxf(xv[jx] + fmaxf(v, 0.f), 0.f);
-                    } else {
-                        if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-                        v *= p.scale;
-                    }
-                    if ((RAFT_WINO4_ABL & 8) && v != 12345.678f) continue;
-                    const unsigned dead = (interior | (rowok[i] & (xb + 4 * r + jx < p.W))) ? 0u : RAFT_OOB;
-                    bstore(v, ro0, vo | dead, (4 * r + jx) * p.ldo0 * 4);
+                    if (mine)
+                        keep[i & 1][jx] = Y[jx];
+                    else
+                        xch[(((((j * 2 + rh) * 4 + (w_e ^ 2)) * 2 + (i & 1)) * 4 + jx) << 6) + (tid_e & 63)] = Y[jx];
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (KS == 2) {   // one exchange per (column block, tile pair), each in its own LDS region: no barrier before the next one's writes
+            raft_barrier_lds();
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                f32x2 Y[4];
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx)
+                    Y[jx] = keep[i2][jx] + xch[(((((j * 2 + rh) * 4 + w_e) * 2 + i2) * 4 + jx) << 6) + (tid_e & 63)];
+                emit(j, i2, rh, Y);
+            }
         }
     });
 }

@@ -13,13 +13,33 @@ int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s) {
         if (M * a.ldo0 * 4 >= lim || (int64_t)36 * (a.c0 + a.c1) * a.npad * 4 >= lim) return RAFT_E_UNSUPPORTED;
         if (epi == EPI_RES && M * a.lde0 * 4 >= lim) return RAFT_E_UNSUPPORTED;
     }
-    const int grid = a.B * ((a.H + 7) / 8) * ((a.W + 63) / 64) * (a.npad / 64);
+    // Two row blocks (8 x 64 pixels) x 64 channels per workgroup; when that leaves fewer workgroups than ~3/4 of the chip's CUs
+    // (fewer than 128: convc2 84, conv 56, fh1 112 at 4 pairs; conv 112 at 8 -- profiles/r07i_wino4_bench.txt), one row block per workgroup with K split between two wave sets instead --
+    // twice the workgroups, half the K loop each (RAFT_WINO4_KS = 1 / 2 overrides).  The split needs an even number of
+    // 16-channel chunks in each source.
+    const int nt = a.npad / 64;
+    const int grid1 = a.B * ((a.H + 7) / 8) * ((a.W + 63) / 64) * nt;
+    const bool ks2_ok = (a.c0 % 32 == 0) && (a.c1 % 32 == 0);
+    int ks = raft_opt(RAFT_OPT_WINO4_KS, grid1 < 128 ? 2 : 1);
+    if (ks != 2 || !ks2_ok) ks = 1;
+    if (ks == 2) {
+        const int grid = a.B * ((a.H + 3) / 4) * ((a.W + 63) / 64) * nt;
+        if (epi == EPI_LINEAR)
+            conv_wino4_kernel<EPI_LINEAR, 2><<<grid, 256, 0, s>>>(a);
+        else if (epi == EPI_RELU)
+            conv_wino4_kernel<EPI_RELU, 2><<<grid, 256, 0, s>>>(a);
+        else if (epi == EPI_RES)
+            conv_wino4_kernel<EPI_RES, 2><<<grid, 256, 0, s>>>(a);
+        else
+            return RAFT_E_UNSUPPORTED;
+        return raft_launch_status();
+    }
     if (epi == EPI_LINEAR)
-        conv_wino4_kernel<EPI_LINEAR><<<grid, 256, 0, s>>>(a);
+        conv_wino4_kernel<EPI_LINEAR, 1><<<grid1, 256, 0, s>>>(a);
     else if (epi == EPI_RELU)
-        conv_wino4_kernel<EPI_RELU><<<grid, 256, 0, s>>>(a);
+        conv_wino4_kernel<EPI_RELU, 1><<<grid1, 256, 0, s>>>(a);
     else if (epi == EPI_RES)
-        conv_wino4_kernel<EPI_RES><<<grid, 256, 0, s>>>(a);
+        conv_wino4_kernel<EPI_RES, 1><<<grid1, 256, 0, s>>>(a);
     else
         return RAFT_E_UNSUPPORTED;
     return raft_launch_status();

@@ -40,13 +40,15 @@ for B in [int(a) for a in sys.argv[1:]] or [4]:
         outs = {}
         flops = 2.0 * B * H * W * 9 * cin * cout
         line = f'  {name:10s} {cin:3d}->{cout:3d}'
-        for kind in ('direct', 'wino2', 'wino4'):
+        for kind in ('direct', 'wino2', 'wino4', 'wino4ks2'):
             if kind == 'direct':
                 wp, b, npad = packing.pack_conv(k, bias)
             elif kind == 'wino2':
                 wp, b, npad = packing.pack_conv_winograd(k, bias)
             else:
                 wp, b, npad = packing.pack_conv_winograd4(k, bias)
+                from tf_raft_amd import _ffi
+                _ffi.set_option('RAFT_WINO4_KS', 2 if kind == 'wino4ks2' else 1)
             wp_d, b_d = _dev.to_device(wp), _dev.to_device(b)
             out = torch.empty((B, H, W, cout), device=x.device)
             if kind == 'direct':
