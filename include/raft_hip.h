@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 210          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 211          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -541,6 +541,17 @@ int raft_norm_backward_f32(const float *x, const float *dy, const float *mean, c
                            int64_t P, int C, float *dx, float *dgamma, float *dbeta, double *workspace, void *stream);
 /* out = relu(alpha * a + beta * b): the residual join of a ResBlock (extractor.py:49). */
 int raft_axpby_relu_f32(float alpha, const float *a, float beta, const float *b, float *out, int64_t n, void *stream);
+
+/* bf16 storage of the training tape (BASELINE configs[4]: "bf16" = bf16 storage, fp32 arithmetic): round-to-nearest-even
+ * narrowing of n floats into n 16-bit words and the exact widening back. */
+int raft_f32_to_bf16(const float *x, void *y, int64_t n, void *stream);
+int raft_bf16_to_f32(const void *x, float *y, int64_t n, void *stream);
+
+/* Keras Dropout in training mode (reference extractor.py:109-111, 127-128): y = x * keep / (1 - rate) with keep ~
+ * Bernoulli(1 - rate) from a counter-based generator of (seed, element index); mask[i] = keep (bytes).  The backward is
+ * dx = dy * mask / (1 - rate).  TensorFlow's random stream is not reproduced: parity of this layer is distributional. */
+int raft_dropout_f32(const float *x, int64_t n, float rate, uint64_t seed, float *y, unsigned char *mask, void *stream);
+int raft_dropout_backward_f32(const float *dy, const unsigned char *mask, int64_t n, float rate, float *dx, void *stream);
 
 /* Backward of raft_upflow8_f32 (corr.py:93-96): d_up (B, 8h, 8w, 2) -> d_flow (B, h, w, 2), a deterministic gather. */
 int raft_upflow8_backward_f32(const float *d_up, int B, int h, int w, float *d_flow, void *stream);

@@ -176,3 +176,31 @@ def test_bench_rejects_a_world_size_that_contradicts_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True,
                          text=True, timeout=120)
     assert out.returncode != 0 and 'WORLD_SIZE=3' in out.stderr
+
+
+def _bn_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from tf_raft_amd.parallel import all_reduce_mean_
+        a = torch.full((3,), float(rank + 1))
+        b = torch.arange(4, dtype=torch.float32).reshape(2, 2) * (rank + 1)
+        all_reduce_mean_([a, b])
+        if rank == 0:
+            np.save(os.path.join(tmp, 'a.npy'), a.numpy())
+            np.save(os.path.join(tmp, 'b.npy'), b.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_statistics_all_reduce_mean(tmp_path):
+    """train_step averages the batch-norm batch statistics over the ranks before the moving-average update (one flattened
+    all-reduce), so that every rank keeps the same moving statistics."""
+    from tf_raft_amd.parallel import all_reduce_mean_
+    mp.spawn(_bn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    np.testing.assert_allclose(np.load(tmp_path / 'a.npy'), np.full(3, 1.5))
+    np.testing.assert_allclose(np.load(tmp_path / 'b.npy'), np.arange(4).reshape(2, 2) * 1.5)
+    t = [torch.ones(2)]
+    assert all_reduce_mean_(t) is t and torch.equal(t[0], torch.ones(2))      # one process: untouched

@@ -653,3 +653,109 @@ def test_small_raft_train_step_matches_reference_semantics(rng):
            rel_l2_of_update=float(np.sqrt(num / den)))
     assert bad / total <= 2e-3 and np.sqrt(num / den) <= 0.1
     assert np.isfinite(model([i1, i2])[-1].numpy()).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# round 3: device-resident parameters, bf16 tape storage, dropout
+# ------------------------------------------------------------------------------------------------------------------------
+def test_loop_with_device_parameters_and_bf16_tape(rng):
+    """(a) grad.* with DEVICE tensors as parameters (what train_step keeps: no host packing) gives bit-for-bit the gradients of
+    the NumPy-parameter path; (b) ``tape_dtype='bf16'`` (BASELINE configs[4]: bf16 storage, fp32 arithmetic) stores every
+    large activation of the tape as bf16: the forward predictions are unchanged (the forward computes in fp32 and only the
+    saved copies are narrowed) and the gradients stay within the stated tolerances of the fp32-tape gradients --
+    5e-3 relative (max norm) on d_net0 / d_inp, 2e-2 in the L2 norm on every weight gradient."""
+    from tf_raft_amd import _dev, grad
+    from tf_raft_amd import weights as wm
+    from tf_raft_amd.layers.corr import CorrBlock
+    B, h, w, C, iters = 2, 16, 24, 32, 3
+    wts_all = wm.condition_weights('raft', wm.init_weights('raft', seed=3, perturb=True), 'mid')
+    wts = {k: v for k, v in wts_all.items() if k.startswith('update_block')}
+    f1 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    f2 = rng.normal(size=(B, h, w, C)).astype(np.float32)
+    net0 = np.tanh(rng.normal(size=(B, h, w, 128))).astype(np.float32)
+    inp = np.maximum(rng.normal(size=(B, h, w, 128)), 0).astype(np.float32)
+    flow_gt = (rng.normal(size=(B, 8 * h, 8 * w, 2)) * 2).astype(np.float32)
+    valid = rng.uniform(size=(B, 8 * h, 8 * w)) < 0.9
+    dev = CorrBlock(f1, f2, 4, 4)
+
+    def run(params, tape_dtype):
+        grad.clear_pack_cache()
+        preds, tape = grad.loop_forward(params, dev, net0, inp, iters, tape_dtype=tape_dtype)
+        d_preds = grad.sequence_loss_grad((flow_gt, valid), preds, gamma=0.8, max_flow=400)
+        d_net0, d_inp, d_pyr, wg = grad.loop_backward(params, dev, tape, d_preds)
+        return [_np(p) for p in preds], _np(d_net0), _np(d_inp), {k: _np(v) for k, v in wg.items()}, tape
+
+    p_np, n_np, i_np, w_np, _ = run(wts, 'f32')
+    dw = {k: _dev.to_device(np.ascontiguousarray(v)).as_subclass(torch.Tensor).clone() for k, v in wts.items()}
+    p_dv, n_dv, i_dv, w_dv, _ = run(dw, 'f32')
+    for a, b_ in zip(p_np, p_dv):
+        np.testing.assert_array_equal(a, b_)
+    np.testing.assert_array_equal(n_np, n_dv)
+    np.testing.assert_array_equal(i_np, i_dv)
+    for k in w_np:
+        np.testing.assert_array_equal(w_np[k], w_dv[k])
+    p_bf, n_bf, i_bf, w_bf, tape = run(dw, 'bf16')
+    for a, b_ in zip(p_np, p_bf):
+        np.testing.assert_array_equal(a, b_)                     # the forward itself is fp32
+    stored = [v for t in tape for v in t['saved'].values() if isinstance(v, tuple)]
+    assert len(stored) >= 10 * iters and all(v[1].dtype == torch.bfloat16 for v in stored)
+    rel = lambda a, b_: float(np.abs(a - b_).max() / max(np.abs(b_).max(), 1e-30))
+    rel2 = lambda a, b_: float(np.linalg.norm((a - b_).astype(np.float64)) / max(np.linalg.norm(b_.astype(np.float64)), 1e-30))
+    worst_w = max(rel2(w_bf[k], w_np[k]) for k in w_np)
+    report('bf16 tape vs fp32 tape', d_net0=rel(n_bf, n_np), d_inp=rel(i_bf, i_np), worst_weight_grad_l2=worst_w,
+           tape_tensors_as_bf16=len(stored))
+    assert rel(n_bf, n_np) <= 5e-3 and rel(i_bf, i_np) <= 5e-3
+    assert worst_w <= 2e-2, {k: rel2(w_bf[k], w_np[k]) for k in w_np if rel2(w_bf[k], w_np[k]) > 5e-3}
+
+
+def test_bf16_casts_round_to_nearest_even_and_dropout_is_a_scaled_mask(rng):
+    from tf_raft_amd import _dev, grad
+    x = np.concatenate([rng.normal(size=4096).astype(np.float32) * 100, np.array([0.0, -0.0, 1.0, 1.00390625, 1.01171875, np.inf, -np.inf,
+                                                                              3.3895314e38], np.float32)])
+    xd = _dev.to_device(x).as_subclass(torch.Tensor)
+    got = grad.to_bf16(xd)
+    want = torch.tensor(x).to(torch.bfloat16)                    # torch's own conversion is round-to-nearest-even
+    assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16))
+    back = _np(grad.from_bf16(got))
+    np.testing.assert_array_equal(back, want.to(torch.float32).numpy())
+    # dropout: reproducible, ~rate of the elements zeroed, survivors scaled by 1 / (1 - rate), backward = the same mask
+    v = _dev.to_device(np.ones((2, 16, 24, 64), np.float32)).as_subclass(torch.Tensor)
+    y, mask = grad.dropout_forward(v, 0.25, seed=11)
+    y2, _ = grad.dropout_forward(v, 0.25, seed=11)
+    y3, _ = grad.dropout_forward(v, 0.25, seed=12)
+    assert torch.equal(y, y2) and not torch.equal(y, y3)
+    yn = _np(y)
+    frac = float((yn == 0).mean())
+    assert abs(frac - 0.25) < 0.01 and set(np.unique(yn)) == {0.0, np.float32(1.0 / 0.75)}
+    dx = _np(grad.dropout_backward(2 * v, mask))
+    np.testing.assert_array_equal(dx, 2 * yn)
+    report('dropout', dropped_fraction=frac)
+
+
+def test_train_step_runs_device_resident_with_dropout_and_bf16_tape(rng):
+    """One full train_step with drop_rate > 0 (reference extractor.py:109-111: Dropout on the encoder outputs) and the bf16
+    tape: finite loss, every trainable tensor moved, the master copies stay on the device (the NumPy dictionary is only
+    refreshed on demand) and a second step continues from them."""
+    import tf_raft_amd
+    from tf_raft_amd import losses, training
+    from tf_raft_amd import weights as wm
+    wts = wm.condition_weights('raft', wm.init_weights('raft', seed=2, perturb=True), 'mid')
+    model = tf_raft_amd.RAFT(drop_rate=0.1, weights=wts, iters=2, iters_pred=2)
+    model.compile(optimizer=training.AdamW(1e-4, 1e-3), clip_norm=1.0, loss=losses.sequence_loss, epe=losses.end_point_error,
+                  tape_dtype='bf16')
+    B, H, W = 2, 64, 96
+    data = (rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32), rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32),
+            (rng.normal(size=(B, H, W, 2)) * 2).astype(np.float32), np.ones((B, H, W), bool))
+    r1 = model.train_step(data)
+    assert model._host_stale and all(v.is_cuda for v in model._dw.values())
+    assert model._weights['update_block/flow_head/conv1/kernel'] is not None     # the host dictionary still holds the OLD values ...
+    np.testing.assert_array_equal(model._weights['fnet/conv1/kernel'], wts['fnet/conv1/kernel'])
+    r2 = model.train_step(data)
+    new = model.get_weights_dict()                                                # ... until somebody asks
+    assert not model._host_stale
+    assert np.isfinite(float(r1['loss'])) and np.isfinite(float(r2['loss']))
+    moved = [k for k in new if not np.array_equal(new[k], wts[k])]
+    assert len(moved) >= 154, len(moved)
+    out = model([data[0], data[1]])                                               # inference re-packs from the trained weights
+    assert np.isfinite(_np(out[-1])).all()
+    report('train_step device-resident, dropout 0.1, bf16 tape', loss1=float(r1['loss']), loss2=float(r2['loss']), tensors_moved=len(moved))

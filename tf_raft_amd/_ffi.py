@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 210     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 211     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -104,6 +104,10 @@ _SIGNATURES = {
     'raft_norm_forward_f32': (_I, [_P, _I, C.c_int64, _I, _P, _P, C.c_float, _I, _P, _P, _P, _P, _P, _P]),
     'raft_norm_backward_f32': (_I, [_P, _P, _P, _P, _P, _I, C.c_int64, _I, _P, _P, _P, _P, _P]),
     'raft_axpby_relu_f32': (_I, [C.c_float, _P, C.c_float, _P, _P, C.c_int64, _P]),
+    'raft_f32_to_bf16': (_I, [_P, _P, C.c_int64, _P]),
+    'raft_bf16_to_f32': (_I, [_P, _P, C.c_int64, _P]),
+    'raft_dropout_f32': (_I, [_P, C.c_int64, C.c_float, C.c_uint64, _P, _P, _P]),
+    'raft_dropout_backward_f32': (_I, [_P, _P, C.c_int64, C.c_float, _P, _P]),
     'raft_upflow8_backward_f32': (_I, [_P, _I, _I, _I, _P, _P]),
     'raft_conv2d_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I,
                              C.c_float, _P, _I, _P]),

@@ -1155,3 +1155,74 @@ extern "C" int raft_upflow8_backward_f32(const float *d_up, int B, int h, int w,
     upflow8_bwd_kernel<<<raft_ceil_div((int64_t)B * h * w, 256), 256, 0, (hipStream_t)stream>>>(d_up, B, h, w, d_flow);
     return raft_launch_status();
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// bf16 storage of the activation tape (BASELINE config 5: bf16 storage, fp32 arithmetic): the training forward keeps what the
+// backward needs as bf16 (round to nearest even) and widens it again before use; every kernel still computes in fp32.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float *__restrict__ x, unsigned short *__restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned u = __float_as_uint(x[i]);
+    // NaN stays NaN (quiet bit), everything else rounds to nearest, ties to even
+    y[i] = ((u & 0x7fffffffu) > 0x7f800000u) ? (unsigned short)((u >> 16) | 0x40u) : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__global__ void __launch_bounds__(256) bf16_to_f32_kernel(const unsigned short *__restrict__ x, float *__restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = __uint_as_float((unsigned)x[i] << 16);
+}
+// counter-based uniform in [0, 1): two rounds of a 64-bit mix (splitmix64 finaliser) of (seed, index)
+__device__ __forceinline__ float dropout_uniform(uint64_t seed, int64_t i) {
+    uint64_t z = (uint64_t)i + seed * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__global__ void __launch_bounds__(256) dropout_kernel(const float *__restrict__ x, int64_t n, float rate, float scale, uint64_t seed,
+                                                      float *__restrict__ y, unsigned char *__restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool keep = dropout_uniform(seed, i) >= rate;
+    mask[i] = keep ? 1 : 0;
+    y[i] = keep ? x[i] * scale : 0.f;
+}
+__global__ void __launch_bounds__(256) dropout_backward_kernel(const float *__restrict__ dy, const unsigned char *__restrict__ mask,
+                                                               int64_t n, float scale, float *__restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = mask[i] ? dy[i] * scale : 0.f;
+}
+}   // namespace
+
+extern "C" int raft_f32_to_bf16(const float *x, void *y, int64_t n, void *stream) {
+    RAFT_REQUIRE_PTR(x); RAFT_REQUIRE_PTR(y);
+    RAFT_REQUIRE(n > 0, RAFT_E_SHAPE);
+    f32_to_bf16_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(x, (unsigned short *)y, n);
+    return raft_launch_status();
+}
+
+extern "C" int raft_bf16_to_f32(const void *x, float *y, int64_t n, void *stream) {
+    RAFT_REQUIRE_PTR(x); RAFT_REQUIRE_PTR(y);
+    RAFT_REQUIRE(n > 0, RAFT_E_SHAPE);
+    bf16_to_f32_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>((const unsigned short *)x, y, n);
+    return raft_launch_status();
+}
+
+// Keras Dropout in training mode (reference extractor.py:109-111, 127-128): y = x * keep / (1 - rate), keep ~ Bernoulli(1 - rate)
+// from a counter-based generator of (seed, element index) -- reproducible, no state; mask[i] = keep (bytes, for the backward).
+// TensorFlow's own random stream cannot be reproduced: the parity of this layer is distributional.
+extern "C" int raft_dropout_f32(const float *x, int64_t n, float rate, uint64_t seed, float *y, unsigned char *mask, void *stream) {
+    RAFT_REQUIRE_PTR(x); RAFT_REQUIRE_PTR(y); RAFT_REQUIRE_PTR(mask);
+    RAFT_REQUIRE(n > 0 && rate >= 0.f && rate < 1.f, RAFT_E_SHAPE);
+    dropout_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(x, n, rate, 1.0f / (1.0f - rate), seed, y, mask);
+    return raft_launch_status();
+}
+
+extern "C" int raft_dropout_backward_f32(const float *dy, const unsigned char *mask, int64_t n, float rate, float *dx, void *stream) {
+    RAFT_REQUIRE_PTR(dy); RAFT_REQUIRE_PTR(mask); RAFT_REQUIRE_PTR(dx);
+    RAFT_REQUIRE(n > 0 && rate >= 0.f && rate < 1.f, RAFT_E_SHAPE);
+    dropout_backward_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(dy, mask, n, 1.0f / (1.0f - rate), dx);
+    return raft_launch_status();
+}

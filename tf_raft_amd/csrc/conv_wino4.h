@@ -67,7 +67,8 @@ __device__ __forceinline__ void w4_static_for(F &&f) {
     X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35)
 
 #ifndef RAFT_WINO4_PF
-#define RAFT_WINO4_PF 4      // weight fragments are fetched this many tap slots (4 MFMAs each) ahead
+#define RAFT_WINO4_PF 7      // weight fragments are fetched this many tap slots (4 MFMAs each) ahead (in the loop the weights are
+                             // cold: 4 slots measured 70 us for convc2 / fh1_mask0 at 4 pairs, 6 - 7 slots 61 - 64, profiles/r07k)
 #endif
 #ifdef RAFT_WINO4_NOSB        // tools/ablate: leave the order of the slot bodies to the compiler
 #define W4_SB()
@@ -542,4 +543,4 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
 
 // launcher (conv_wino4.hip); `a.wp` holds the F(4x4, 3x3)-transformed weights in consumption order
 // (Cin/16, 72, 4, npad/32, 16, 2, 2) -- tf_raft_amd/packing.py pack_conv_winograd4.  epi: EPI_LINEAR / EPI_RELU / EPI_RES.
-int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s);
+int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide_npad = 0);

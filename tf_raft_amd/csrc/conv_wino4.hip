@@ -1,7 +1,7 @@
 // Winograd F(4x4, 3x3) convolution launcher (kernel: conv_wino4.h).
 #include "conv_wino4.h"
 
-int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s) {
+int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide_npad) {
     if (a.c0 <= 0 || a.c0 % 16 || a.c1 < 0 || a.c1 % 16 || a.npad <= 0 || a.npad % 64) return RAFT_E_UNSUPPORTED;
     if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
     if (!raft_aligned16(a.a0) || !raft_aligned16(a.wp) || (a.c1 && !raft_aligned16(a.a1))) return RAFT_E_ALIGN;
@@ -19,8 +19,11 @@ int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s) {
     // 16-channel chunks in each source.
     const int nt = a.npad / 64;
     const int grid1 = a.B * ((a.H + 7) / 8) * ((a.W + 63) / 64) * nt;
+    // decide_npad: choose the variant as a layer of that many output channels would (flow_head.conv1 alone must round exactly
+    // like its half of the fused flow / mask head: RAFT.predict_step returns the bits of flow_predictions[-1])
+    const int grid_decide = decide_npad > 0 ? grid1 / nt * (decide_npad / 64) : grid1;
     const bool ks2_ok = (a.c0 % 32 == 0) && (a.c1 % 32 == 0);
-    int ks = raft_opt(RAFT_OPT_WINO4_KS, grid1 < 128 ? 2 : 1);
+    int ks = raft_opt(RAFT_OPT_WINO4_KS, grid_decide < 128 ? 2 : 1);
     if (ks != 2 || !ks2_ok) ks = 1;
     if (ks == 2) {
         const int grid = a.B * ((a.H + 3) / 4) * ((a.W + 63) / 64) * nt;

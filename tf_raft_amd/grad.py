@@ -45,6 +45,57 @@ def _cached(arr, tag, make, also=None):
     return hit[2]
 
 
+# Parameters may be NumPy arrays in Keras layout (the weight dictionaries of the models) or fp32 DEVICE tensors (the master
+# copies ``train_step`` keeps: nothing of a training step then touches the host).  Packing for the convolution kernels is done
+# where the parameter lives: ``packing`` on the host, the same index shuffles as torch views / copies on the device.
+def _is_t(v):
+    return isinstance(v, torch.Tensor)
+
+
+def _cat(parts, axis):
+    return torch.cat(list(parts), dim=axis) if _is_t(parts[0]) else np.concatenate(list(parts), axis=axis)
+
+
+def _params(weights, prefix):
+    """Parameters under ``prefix``: device tensors are passed through AS THE SAME OBJECTS (the pack cache is keyed on
+    identity), anything else becomes a float32 NumPy array."""
+    return {k: (v if type(v) is torch.Tensor else (v.as_subclass(torch.Tensor) if _is_t(v) else np.asarray(v, dtype=np.float32)))
+            for k, v in weights.items() if k.startswith(prefix)}
+
+
+def _dev_param(v):
+    """fp32 device tensor of a parameter (no copy when it already is one)."""
+    return v.as_subclass(torch.Tensor) if _is_t(v) else _dev.to_device(np.ascontiguousarray(v, dtype=np.float32)).as_subclass(torch.Tensor)
+
+
+def _pack_conv_any(kernel, bias, sources):
+    """``packing.pack_conv`` -> (wp, bias, npad) as device tensors, computed on the device for device parameters."""
+    if not _is_t(kernel):
+        wp, b, npad = packing.pack_conv(kernel, bias if bias is not None else np.zeros(kernel.shape[3], np.float32), sources)
+        return _dev.to_device(wp), _dev.to_device(b), npad
+    kh, kw, cin, cout = kernel.shape
+    kpad, npad = sum(cp for _, cp in sources), packing.round_up(cout, 64)
+    full = torch.zeros((kh * kw, kpad, npad), device=kernel.device, dtype=torch.float32)
+    flat = kernel.reshape(kh * kw, cin, cout)
+    k_src = k_dst = 0
+    for c, cp in sources:
+        full[:, k_dst:k_dst + c, :cout] = flat[:, k_src:k_src + c, :]
+        k_src += c
+        k_dst += cp
+    wp = full.reshape(kh * kw, kpad // 4, 4, npad).permute(0, 1, 3, 2).contiguous()
+    b = torch.zeros((npad,), device=kernel.device, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = _dev_param(bias)
+    return wp, b, npad
+
+
+def _dgrad_kernel_any(kernel):
+    """``packing.dgrad_kernel``: spatial flip, in / out channels transposed."""
+    if not _is_t(kernel):
+        return packing.dgrad_kernel(kernel)
+    return kernel.flip(0, 1).permute(0, 1, 3, 2).contiguous()
+
+
 def sequence_loss_grad(y_true, y_pred, gamma=0.8, max_flow=400, upstream=1.0):
     """d ``sequence_loss(y_true, y_pred)`` / d ``y_pred[i]`` for every i (reference losses.py:4-21): list of tensors shaped
     like the predictions."""
@@ -95,7 +146,7 @@ def conv2d_backward(x, kernel, dy, y=None):
     Cin and Cout must be multiples of 4 (every layer of the update block except the flow-carrying ones)."""
     x = _f32(x)
     dy = _f32(dy)
-    kernel = np.asarray(kernel, dtype=np.float32)
+    kernel = (kernel if type(kernel) is torch.Tensor else kernel.as_subclass(torch.Tensor)) if _is_t(kernel) else np.asarray(kernel, dtype=np.float32)
     kh, kw, cin, cout = kernel.shape
     B, H, W, _ = x.shape
     if x.shape[-1] != cin or tuple(dy.shape) != (B, H, W, cout):
@@ -117,10 +168,7 @@ def conv2d_backward(x, kernel, dy, y=None):
     # input gradient: the forward convolution of dy with the flipped, transposed kernel
     cpad = packing.round_up(cout, 32)
 
-    def make():
-        wp, b, npad_ = packing.pack_conv_dgrad(kernel, [(cout, cpad)])
-        return _dev.to_device(wp), _dev.to_device(b), npad_
-    wp_d, b_d, npad = _cached(kernel, 'dgrad', make)
+    wp_d, b_d, npad = _cached(kernel, 'dgrad', lambda: _pack_conv_any(_dgrad_kernel_any(kernel), None, [(cout, cpad)]))
     dyp = dy
     if cpad != cout:
         dyp = torch.zeros((B, H, W, cpad), device=x.device, dtype=torch.float32)
@@ -137,15 +185,12 @@ def conv2d_backward(x, kernel, dy, y=None):
 
 def _conv_fwd(x, kernel, bias, act=0, scale=1.0):
     """``[relu](conv2d(x, kernel) + bias) * scale`` through ``raft_conv2d_f32`` (stride 1, 'same'); x (B, H, W, Cin)."""
-    kernel = np.asarray(kernel, dtype=np.float32)
+    kernel = (kernel if type(kernel) is torch.Tensor else kernel.as_subclass(torch.Tensor)) if _is_t(kernel) else np.asarray(kernel, dtype=np.float32)
     kh, kw, cin, cout = kernel.shape
     B, H, W, c = x.shape
     cpad = packing.round_up(cin, 32)
-
-    def make():
-        wp, b, npad_ = packing.pack_conv(kernel, bias, [(cin, cpad)])
-        return _dev.to_device(wp), _dev.to_device(b), npad_
-    wp_d, b_d, npad = _cached(kernel, 'fwd', make, also=bias) if isinstance(bias, np.ndarray) else make()
+    make = lambda: _pack_conv_any(kernel, bias, [(cin, cpad)])
+    wp_d, b_d, npad = _cached(kernel, 'fwd', make, also=bias) if isinstance(bias, (np.ndarray, torch.Tensor)) else make()
     xp = x
     if cpad != c:
         xp = torch.zeros((B, H, W, cpad), device=x.device, dtype=torch.float32)
@@ -165,12 +210,13 @@ def _axpby(alpha, a, beta=0.0, b=None):
 
 def _conv_bwd(x, kernel, dy, y=None):
     """``conv2d_backward`` for any channel counts: pads Cin / Cout to multiples of 4 around the kernels and trims."""
-    kernel = np.asarray(kernel, dtype=np.float32)
+    kernel = (kernel if type(kernel) is torch.Tensor else kernel.as_subclass(torch.Tensor)) if _is_t(kernel) else np.asarray(kernel, dtype=np.float32)
     kh, kw, cin, cout = kernel.shape
     ci4, co4 = packing.round_up(cin, 4), packing.round_up(cout, 4)
     if ci4 != cin or co4 != cout:
         def pad():
-            kp_ = np.zeros((kh, kw, ci4, co4), np.float32)
+            kp_ = (torch.zeros((kh, kw, ci4, co4), device=kernel.device, dtype=torch.float32) if _is_t(kernel)
+                   else np.zeros((kh, kw, ci4, co4), np.float32))
             kp_[:, :, :cin, :cout] = kernel
             return kp_
         kp = _cached(kernel, 'pad4', pad)
@@ -206,7 +252,7 @@ def update_block_forward(weights, net, inp, corr, flow, prefix='update_block', v
     lib = _dev.lib()
     p, cfg = prefix, _UB[variant]
     hd = cfg['hdim']
-    w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p)}
+    w = _params(weights, p)
     net, inp, corr, flow = (_f32(t) for t in (net, inp, corr, flow))
     B, H, W, _ = net.shape
     M = B * H * W
@@ -215,8 +261,8 @@ def update_block_forward(weights, net, inp, corr, flow, prefix='update_block', v
     s['cor1'] = conv('encoder/convc1', corr, 1)
     s['cor2'] = conv('encoder/convc2', s['cor1'], 1) if cfg['convc2'] else s['cor1']
     cf1 = cfg['cf1']
-    k7 = _cached(w[f'{p}/encoder/convf1/kernel'], 'k7', lambda: _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, cf1)))
-    b7 = _cached(w[f'{p}/encoder/convf1/bias'], 'b7', lambda: _dev.to_device(w[f'{p}/encoder/convf1/bias']))
+    k7 = _cached(w[f'{p}/encoder/convf1/kernel'], 'k7', lambda: _dev_param(w[f'{p}/encoder/convf1/kernel']).reshape(98, cf1).contiguous())
+    b7 = _cached(w[f'{p}/encoder/convf1/bias'], 'b7', lambda: _dev_param(w[f'{p}/encoder/convf1/bias']))
     s['flo1'] = torch.empty((B, H, W, cf1), device=net.device, dtype=torch.float32)
     check(lib.raft_conv7x7_c2_f32(_dev.ptr(flow), _dev.ptr(k7), _dev.ptr(b7), cf1, B, H, W, _dev.ptr(s['flo1']), cf1,
                                   _dev.stream_ptr()), 'conv7x7_c2')
@@ -227,10 +273,10 @@ def update_block_forward(weights, net, inp, corr, flow, prefix='update_block', v
     s['x'] = x
     h = net
     for g in cfg['gru']:                                                           # update.py:51-67 / 26-35
-        kzr = _cached(w[f'{p}/gru/convz{g}/kernel'], 'kzr', lambda: np.concatenate(
-            [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3), also=w[f'{p}/gru/convr{g}/kernel'])
-        bzr = _cached(w[f'{p}/gru/convz{g}/bias'], 'bzr', lambda: np.concatenate(
-            [w[f'{p}/gru/convz{g}/bias'], w[f'{p}/gru/convr{g}/bias']]), also=w[f'{p}/gru/convr{g}/bias'])
+        kzr = _cached(w[f'{p}/gru/convz{g}/kernel'], 'kzr', lambda: _cat(
+            [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], 3), also=w[f'{p}/gru/convr{g}/kernel'])
+        bzr = _cached(w[f'{p}/gru/convz{g}/bias'], 'bzr', lambda: _cat(
+            [w[f'{p}/gru/convz{g}/bias'], w[f'{p}/gru/convr{g}/bias']], 0), also=w[f'{p}/gru/convr{g}/bias'])
         hx = torch.cat([h, x], dim=-1).contiguous()
         a_zr = _conv_fwd(hx, kzr, bzr)
         z, r, rh = (torch.empty_like(h) for _ in range(3))
@@ -267,7 +313,7 @@ def update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update
     s = saved
     cfg = _UB[s['variant']]
     hd, cd, mot = cfg['hdim'], cfg['cdim'], cfg['mot']
-    w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p)}
+    w = _params(weights, p)
     d_net, d_delta = _f32(d_net), _f32(d_delta)
     grads = {}
     B, H, W, _ = d_net.shape
@@ -302,8 +348,8 @@ def update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update
         dr_pre = torch.empty_like(h_in)
         check(lib.raft_gru_gate_r_backward_f32(_dev.ptr(d_rh), _dev.ptr(r), _dev.ptr(h_in), n_h, _dev.ptr(dr_pre), _dev.ptr(dh_in),
                                                _dev.stream_ptr()), 'gate_r_backward')
-        kzr = _cached(w[f'{p}/gru/convz{g}/kernel'], 'kzr', lambda: np.concatenate(
-            [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], axis=3), also=w[f'{p}/gru/convr{g}/kernel'])
+        kzr = _cached(w[f'{p}/gru/convz{g}/kernel'], 'kzr', lambda: _cat(
+            [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], 3), also=w[f'{p}/gru/convr{g}/kernel'])
         d_zr = torch.cat([dz_pre, dr_pre], dim=-1).contiguous()
         d_hx, dk, db = conv_b(None, s[f'hx{g}'], d_zr, kernel=kzr)
         grads[f'{p}/gru/convz{g}/kernel'], grads[f'{p}/gru/convr{g}/kernel'] = dk[..., :hd].contiguous(), dk[..., hd:].contiguous()
@@ -328,7 +374,7 @@ def update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update
     check(lib.raft_relu_backward_f32(_dev.ptr(s['flo1']), _dev.ptr(d_flo1), _dev.ptr(masked), masked.numel(), _dev.stream_ptr()),
           'relu_backward')
     cf1 = cfg['cf1']
-    k7 = _cached(w[f'{p}/encoder/convf1/kernel'], 'k7', lambda: _dev.to_device(np.ascontiguousarray(w[f'{p}/encoder/convf1/kernel']).reshape(98, cf1)))
+    k7 = _cached(w[f'{p}/encoder/convf1/kernel'], 'k7', lambda: _dev_param(w[f'{p}/encoder/convf1/kernel']).reshape(98, cf1).contiguous())
     d_flow_f = torch.empty((B, H, W, 2), device=d_net.device, dtype=torch.float32)
     dk7 = torch.empty((98, cf1), device=d_net.device, dtype=torch.float32)
     db7 = torch.empty((cf1,), device=d_net.device, dtype=torch.float32)
@@ -369,11 +415,64 @@ def upflow8_backward(d_up, B, h, w):
     return out
 
 
-def loop_forward(weights, corr_block, net0, inp, iters, prefix='update_block', variant='raft'):
+def to_bf16(t):
+    """bf16 copy of an fp32 device tensor (round to nearest even, ``raft_f32_to_bf16``)."""
+    t = t.as_subclass(torch.Tensor).contiguous()
+    out = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    check(_dev.lib().raft_f32_to_bf16(_dev.ptr(t), _dev.ptr(out), t.numel(), _dev.stream_ptr()), 'f32_to_bf16')
+    return out
+
+
+def from_bf16(t):
+    out = torch.empty(t.shape, device=t.device, dtype=torch.float32)
+    check(_dev.lib().raft_bf16_to_f32(_dev.ptr(t), _dev.ptr(out), t.numel(), _dev.stream_ptr()), 'bf16_to_f32')
+    return out
+
+
+_TAPE_KEEP_F32 = 4096      # tensors smaller than this many elements per pixel-batch stay fp32 (coordinates, flow: 2 channels)
+
+
+def _tape_narrow(saved):
+    """The saved activations of one iteration with every large fp32 tensor stored as bf16 (half the tape memory)."""
+    out = {}
+    for k, v in saved.items():
+        if _is_t(v) and v.dtype == torch.float32 and v.dim() == 4 and v.shape[-1] >= 8:
+            out[k] = ('bf16', to_bf16(v))
+        else:
+            out[k] = v
+    return out
+
+
+def _tape_widen(saved):
+    return {k: (from_bf16(v[1]) if isinstance(v, tuple) and v[0] == 'bf16' else v) for k, v in saved.items()}
+
+
+def dropout_forward(x, rate, seed):
+    """Keras Dropout, training mode (reference extractor.py:109-111): ``(y, mask)``."""
+    x = x.as_subclass(torch.Tensor).contiguous()
+    y = torch.empty_like(x)
+    mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    check(_dev.lib().raft_dropout_f32(_dev.ptr(x), x.numel(), float(rate), int(seed), _dev.ptr(y), _dev.ptr(mask), _dev.stream_ptr()),
+          'dropout')
+    return y, (mask, float(rate))
+
+
+def dropout_backward(dy, mask):
+    dy = dy.as_subclass(torch.Tensor).contiguous()
+    dx = torch.empty_like(dy)
+    check(_dev.lib().raft_dropout_backward_f32(_dev.ptr(dy), _dev.ptr(mask[0]), dy.numel(), mask[1], _dev.ptr(dx), _dev.stream_ptr()),
+          'dropout_backward')
+    return dx
+
+
+def loop_forward(weights, corr_block, net0, inp, iters, prefix='update_block', variant='raft', tape_dtype='f32'):
     """The ``for i in range(iters)`` loop of ``RAFT.call`` (reference model.py:91-109) in training form, from the correlation
     volume, ``net0 = tanh(.)`` and ``inp = relu(.)`` on: lookup -> update block -> coords1 += delta -> convex upsampling.
-    Returns ``(flow_predictions, tape)``; the tape holds what ``loop_backward`` needs."""
+    Returns ``(flow_predictions, tape)``; the tape holds what ``loop_backward`` needs -- with ``tape_dtype='bf16'`` every large
+    activation of it is STORED as bf16 and widened again by the backward (all arithmetic stays fp32)."""
     from .layers.corr import coords_grid
+    if tape_dtype not in ('f32', 'bf16'):
+        raise ValueError(f"tape_dtype must be 'f32' or 'bf16', got {tape_dtype!r}")
     net, inp = _f32(net0), _f32(inp)
     B, h, w, _ = net.shape
     coords0 = coords_grid(B, h, w).as_subclass(torch.Tensor)
@@ -393,7 +492,12 @@ def loop_forward(weights, corr_block, net0, inp, iters, prefix='update_block', v
                   'upsample_convex')
         else:                                                                       # SmallRAFT: model.py:223
             check(lib.raft_upflow8_f32(_dev.ptr(flow_n), B, h, w, _dev.ptr(up), _dev.stream_ptr()), 'upflow8')
-        tape.append(dict(coords1=coords1, saved=saved, flow_n=flow_n, mask=mask))
+        if tape_dtype == 'bf16':
+            saved = _tape_narrow(saved)
+            mask_t = ('bf16', to_bf16(mask)) if mask is not None else None
+        else:
+            mask_t = mask
+        tape.append(dict(coords1=coords1, saved=saved, flow_n=flow_n, mask=mask_t))
         preds.append(_dev.wrap(up))
         net, coords1 = net_n.as_subclass(torch.Tensor), coords_n
     return preds, tape
@@ -411,15 +515,17 @@ def loop_backward(weights, corr_block, tape, d_preds, prefix='update_block'):
     wg = None
     for i in reversed(range(iters)):
         t = tape[i]
-        if t['mask'] is not None:
-            d_flowlow, d_mask = upsample_flow_backward(t['flow_n'], t['mask'], d_preds[i])
+        saved = _tape_widen(t['saved'])
+        mask_i = from_bf16(t['mask'][1]) if isinstance(t['mask'], tuple) else t['mask']
+        if mask_i is not None:
+            d_flowlow, d_mask = upsample_flow_backward(t['flow_n'], mask_i, d_preds[i])
         else:
             B_, h_, w_, _ = t['flow_n'].shape
             d_flowlow, d_mask = upflow8_backward(d_preds[i], B_, h_, w_), None
         d_c = d_flowlow if d_c is None else _axpby(1.0, d_c, 1.0, d_flowlow)
         if d_net is None:
-            d_net = torch.zeros_like(t['saved']['net'])
-        din, dw = update_block_backward(weights, t['saved'], d_net, d_mask, d_c, prefix)
+            d_net = torch.zeros_like(saved['net'])
+        din, dw = update_block_backward(weights, saved, d_net, d_mask, d_c, prefix)
         d_coords, d_pyr = corr_lookup_backward(corr_block, t['coords1'], din['corr'], d_pyramid=d_pyr)
         d_c = _axpby(1.0, d_c, 1.0, din['flow'].as_subclass(torch.Tensor))
         d_c = _axpby(1.0, d_c, 1.0, d_coords.as_subclass(torch.Tensor))
@@ -489,7 +595,7 @@ def _norm_fwd(x, gamma, beta, per_sample, relu):
     lib = _dev.lib()
     B, H, W, C_ = x.shape
     G, P = (B, H * W) if per_sample else (1, B * H * W)
-    g_d, b_d = _dev.to_device(np.asarray(gamma, np.float32)), _dev.to_device(np.asarray(beta, np.float32))
+    g_d, b_d = _dev_param(gamma), _dev_param(beta)
     y = torch.empty_like(x)
     mean, rstd, var = (torch.empty((G, C_), device=x.device, dtype=torch.float32) for _ in range(3))
     ws = torch.empty((int(lib.raft_norm_workspace_doubles(G, C_)),), device=x.device, dtype=torch.float64)
@@ -559,7 +665,7 @@ def encoder_forward(weights, prefix, x, training=True):
     normalisation uses batch statistics when ``training`` (Keras), instance normalisation is the same in both modes.
     Returns ``(out, tape)``."""
     p = prefix
-    w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p + '/')}
+    w = _params(weights, p + '/')
     x = _f32(x)
     tape = {'layers': []}
 
@@ -579,7 +685,8 @@ def encoder_forward(weights, prefix, x, training=True):
 
     k1 = w[f'{p}/conv1/kernel']                                             # (7, 7, 3, c0): stem as a 1x1 conv over im2col
     cols = _stem_cols(x)
-    kcol = np.ascontiguousarray(k1.transpose(2, 0, 1, 3).reshape(1, 1, 147, k1.shape[3]))
+    kcol = (k1.permute(2, 0, 1, 3).reshape(1, 1, 147, k1.shape[3]).contiguous() if _is_t(k1)
+            else np.ascontiguousarray(k1.transpose(2, 0, 1, 3).reshape(1, 1, 147, k1.shape[3])))
     c = _conv_fwd(cols, kcol, w[f'{p}/conv1/bias'])
     y, nc = norm('norm1', c, True)
     tape['stem'] = dict(cols=cols, kcol=kcol, norm=nc)
@@ -613,7 +720,7 @@ def encoder_backward(weights, prefix, tape, d_out):
     weight names; the input image receives none).  Also returns the batch statistics of every batch-norm layer
     (``{name: (mean, biased variance, element count)}``) for the moving-average update."""
     p = prefix
-    w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(p + '/')}
+    w = _params(weights, p + '/')
     g, stats = {}, {}
 
     def norm_b(name, cache, dy):

@@ -89,6 +89,7 @@ class RAFT:
         self._weights = dict(weights)
         self._inference_stale = False
         self._train_vars = None                     # train_step re-reads its device master copies
+        self._dw, self._host_stale = None, False
         self.fnet.set_weights(weights)
         self.cnet.set_weights(weights)
         self.update_block.set_weights(weights)
@@ -103,14 +104,23 @@ class RAFT:
         else:
             self.set_weights(weights_mod.load_weights(path))
 
+    def _sync_host(self):
+        """``train_step`` keeps the master weights (and the batch-norm moving statistics) on the device and updates them in
+        place; the NumPy dictionary is refreshed from them only when somebody asks for it (checkpoint, inference re-pack)."""
+        if getattr(self, '_host_stale', False) and self._dw is not None:
+            self._weights = {k: v.detach().cpu().numpy() for k, v in self._dw.items()}
+            self._host_stale = False
+
     def get_weights_dict(self) -> Dict[str, np.ndarray]:
         """The current weights in Keras layout under ``tf_raft_amd.weights`` names."""
+        self._sync_host()
         return dict(self._weights)
 
     def save_weights(self, path: str) -> None:
         """reference train_sintel.py:104-107 (ModelCheckpoint(save_weights_only=True)): ``path`` ending in ``.npz``
         writes the NumPy container, anything else a TensorFlow tensor-bundle checkpoint prefix."""
         from . import checkpoint
+        self._sync_host()
         if path.endswith('.npz'):
             weights_mod.save_weights(path, self._weights)
         else:
@@ -237,9 +247,10 @@ class RAFT:
 
     def _sync_inference_weights(self):
         if getattr(self, '_inference_stale', False):
-            keep = self._train_vars
+            self._sync_host()
+            keep = (self._train_vars, self._dw)
             self.set_weights(self._weights)
-            self._train_vars = keep
+            self._train_vars, self._dw = keep
             self._inference_stale = False
 
     def _forward(self, inputs, training=False, final_only=False):
@@ -368,7 +379,7 @@ class RAFT:
         return np.concatenate(results, axis=0)
 
     # ---- evaluation plumbing (reference model.py:111-170)
-    def compile(self, optimizer=None, clip_norm=None, loss=None, epe=None, trainable='all', **kwargs):
+    def compile(self, optimizer=None, clip_norm=None, loss=None, epe=None, trainable='all', tape_dtype='f32', **kwargs):
         """reference model.py:111-124.  ``loss`` / ``epe`` default to ``tf_raft_amd.losses.sequence_loss`` /
         ``end_point_error``.  ``trainable``: which weights ``train_step`` updates -- ``'all'`` (the reference's behaviour:
         encoders, norms and update block) or ``'update_block'`` (encoders frozen, run by the inference kernels)."""
@@ -377,12 +388,15 @@ class RAFT:
             raise TypeError(f'unexpected keyword arguments {sorted(kwargs)}')
         if trainable not in ('all', 'update_block'):
             raise ValueError(f"trainable must be 'all' or 'update_block', got {trainable!r}")
+        if tape_dtype not in ('f32', 'bf16'):     # bf16: the loop's activation tape is STORED as bf16 (BASELINE configs[4]), fp32 arithmetic
+            raise ValueError(f"tape_dtype must be 'f32' or 'bf16', got {tape_dtype!r}")
         self.optimizer = optimizer
         self.clip_norm = clip_norm
         self.loss = loss if loss is not None else losses.sequence_loss
         self.epe = epe if epe is not None else losses.end_point_error
         self.trainable = trainable
         self._train_vars = None
+        self.tape_dtype = tape_dtype
         self.flow_metrics = OrderedDict((k, losses.Mean(name=k)) for k in ('loss', 'epe', 'u1', 'u3', 'u5'))
 
     BN_MOMENTUM = 0.99      # Keras BatchNormalization default (extractor.py:10 passes none)
@@ -400,9 +414,6 @@ class RAFT:
             raise RuntimeError('call compile() before train_step()')
         if self.loss is not losses.sequence_loss:
             raise NotImplementedError('train_step differentiates tf_raft_amd.losses.sequence_loss only')
-        if self.drop_rate:
-            raise NotImplementedError('train_step with drop_rate > 0 (the Dropout layer at the encoder outputs, extractor.py:109-111, '
-                                      '127-128) is not built; the reference trains with drop_rate=0 (train_sintel.py:96)')
         if self.optimizer is None or not hasattr(self.optimizer, 'apply_gradients'):
             raise RuntimeError('compile() needs an optimizer with apply_gradients(grads, variables, clip_norm) '
                                '(tf_raft_amd.training.AdamW)')
@@ -414,17 +425,33 @@ class RAFT:
             raise ValueError(f'H and W must be multiples of 8 (got {H}x{W})')
         h, w = H // 8, W // 8
         full = self.trainable == 'all'
-        wts = self._weights
+        # Master copies of EVERY weight (and the batch-norm moving statistics) live on the device from the first step on and
+        # are updated in place; grad.* packs them for the convolution kernels on the device too.  Nothing of a step crosses
+        # PCIe except the input batch (get_weights_dict / save_weights / the next inference call pull them back lazily).
+        if self._dw is None:
+            self._dw = {k: _dev.to_device(np.ascontiguousarray(v, dtype=np.float32)).as_subclass(torch.Tensor).clone()
+                        for k, v in self._weights.items()}
+        wts = self._dw
         grad.clear_pack_cache()                     # packed copies of last step's weights
+        drop_masks = []
         if full:
             ones = torch.ones_like(image1)
             x1 = grad._axpby(2.0 / 255.0, image1.contiguous(), -1.0, ones)            # model.py:70-71
             x2 = grad._axpby(2.0 / 255.0, image2.contiguous(), -1.0, ones)
             fout, ftape = grad.encoder_forward(wts, 'fnet', torch.cat([x1, x2], dim=0), training=True)     # model.py:74
             fout = fout.as_subclass(torch.Tensor)
-            fmap1, fmap2 = fout[:B].contiguous(), fout[B:].contiguous()
             cnet, ctape = grad.encoder_forward(wts, 'cnet', x1, training=True)         # model.py:82
+            cnet = cnet.as_subclass(torch.Tensor)
+            if self.drop_rate:     # extractor.py:109-111, 127-128: Dropout on the encoder outputs while training
+                self._drop_step = getattr(self, '_drop_step', 0) + 1
+                fout, mf = grad.dropout_forward(fout, self.drop_rate, seed=2 * self._drop_step)
+                cnet, mc = grad.dropout_forward(cnet, self.drop_rate, seed=2 * self._drop_step + 1)
+                drop_masks = [mf, mc]
+            fmap1, fmap2 = fout[:B].contiguous(), fout[B:].contiguous()
         else:
+            if self.drop_rate:
+                raise NotImplementedError("drop_rate > 0 with trainable='update_block': dropout sits on the (frozen) encoder "
+                                          "outputs; train all weights or use drop_rate=0")
             fmap1, fmap2 = self.fnet([image1, image2], training=False, _raw_images=True)
             cnet = self.cnet(image1, training=False, _raw_images=True)
         correlation = CorrBlock(fmap1, fmap2, num_levels=self.corr_levels, radius=self.corr_radius)   # model.py:77
@@ -435,7 +462,7 @@ class RAFT:
         inp = st.x[..., :self.context_dim].contiguous()
         prefix = 'update_block'
         ub = {k: v for k, v in wts.items() if k.startswith(prefix)}
-        preds, tape = grad.loop_forward(ub, correlation, net0, inp, self.iters, prefix, self.variant)
+        preds, tape = grad.loop_forward(ub, correlation, net0, inp, self.iters, prefix, self.variant, tape_dtype=self.tape_dtype)
         loss = self.loss([flow, valid], preds)
         d_preds = grad.sequence_loss_grad((flow, valid), preds)
         d_net0, d_inp, d_pyr, grads = grad.loop_backward(ub, correlation, tape, d_preds, prefix)
@@ -443,31 +470,36 @@ class RAFT:
         if full:
             d_f1, d_f2 = grad.corr_build_backward(correlation, d_pyr)
             d_fout = torch.cat([d_f1.as_subclass(torch.Tensor), d_f2.as_subclass(torch.Tensor)], dim=0).contiguous()
-            gf, _ = grad.encoder_backward(wts, 'fnet', ftape, d_fout)
             d_cnet = grad.prepare_state_backward(net0, inp, d_net0, d_inp)
+            if drop_masks:
+                d_fout = grad.dropout_backward(d_fout, drop_masks[0])
+                d_cnet = grad.dropout_backward(d_cnet.as_subclass(torch.Tensor).contiguous(), drop_masks[1])
+            gf, _ = grad.encoder_backward(wts, 'fnet', ftape, d_fout)
             gc, stats = grad.encoder_backward(wts, 'cnet', ctape, d_cnet)
             grads = dict(grads)
             grads.update(gf)
             grads.update(gc)
         names = sorted(grads)
-        if self._train_vars is None or sorted(self._train_vars) != names:
-            self._train_vars = {k: _dev.to_device(np.ascontiguousarray(wts[k])).as_subclass(torch.Tensor).clone() for k in names}
-        gt = {k: grads[k].as_subclass(torch.Tensor).reshape(self._train_vars[k].shape).contiguous() for k in names}
-        from .parallel import all_reduce_gradients
+        self._train_vars = {k: wts[k] for k in names}          # views of the device master copies (updated in place)
+        gt = {k: grads[k].as_subclass(torch.Tensor).reshape(wts[k].shape).contiguous() for k in names}
+        from .parallel import all_reduce_gradients, all_reduce_mean_
         all_reduce_gradients(gt)                    # data-parallel training: one bucketed RCCL all-reduce (no-op on one rank)
         self.optimizer.apply_gradients(gt, self._train_vars, clip_norm=self.clip_norm)
-        for k, v in self._train_vars.items():
-            wts[k] = v.detach().cpu().numpy()
-        # Keras BatchNormalization moving statistics (momentum 0.99).  TF 2.3's fused kernel feeds the moving variance with
-        # the UNBIASED batch variance; that detail cannot be checked here (no TensorFlow) and is stated in DESIGN.md.
-        for name, (mean, var, cnt) in stats.items():
-            mm = _dev.to_device(np.ascontiguousarray(wts[f'{name}/moving_mean'])).as_subclass(torch.Tensor)
-            mv = _dev.to_device(np.ascontiguousarray(wts[f'{name}/moving_variance'])).as_subclass(torch.Tensor)
-            wts[f'{name}/moving_mean'] = grad._axpby(self.BN_MOMENTUM, mm, 1.0 - self.BN_MOMENTUM, mean.contiguous()).cpu().numpy()
-            wts[f'{name}/moving_variance'] = grad._axpby(self.BN_MOMENTUM, mv, (1.0 - self.BN_MOMENTUM) * cnt / max(cnt - 1.0, 1.0),
-                                                         var.contiguous()).cpu().numpy()
-        # the inference kernels take re-packed (Winograd-transformed, N-fused) copies: made lazily by the next forward call
-        self._weights = dict(wts)
+        # Keras BatchNormalization moving statistics (momentum 0.99), in place on the device.  TF 2.3's fused kernel feeds the
+        # moving variance with the UNBIASED batch variance; that detail cannot be checked here (no TensorFlow) and is stated in
+        # DESIGN.md.  Data-parallel: the batch statistics are averaged over the ranks first (one small all-reduce), so that
+        # every rank keeps the same moving statistics and a checkpoint does not depend on which rank writes it.
+        if stats:
+            order = sorted(stats)
+            all_reduce_mean_([t for name in order for t in (stats[name][0], stats[name][1])])
+            for name in order:
+                mean, var, cnt = stats[name]
+                mm, mv = wts[f'{name}/moving_mean'], wts[f'{name}/moving_variance']
+                mm.copy_(grad._axpby(self.BN_MOMENTUM, mm, 1.0 - self.BN_MOMENTUM, mean.contiguous()))
+                mv.copy_(grad._axpby(self.BN_MOMENTUM, mv, (1.0 - self.BN_MOMENTUM) * cnt / max(cnt - 1.0, 1.0), var.contiguous()))
+        # the NumPy dictionary and the inference kernels' re-packed (Winograd-transformed, N-fused) copies are refreshed
+        # lazily: by get_weights_dict / save_weights, and by the next forward call
+        self._host_stale = True
         self._inference_stale = True
         info = self.epe([flow, valid], preds[-1])
         self.flow_metrics['loss'].update_state(loss)

@@ -163,3 +163,18 @@ def all_reduce_gradients(grads, group=None, bucket_bytes: int = 64 << 20):
         size += nbytes
     flush()
     return grads
+
+
+def all_reduce_mean_(tensors, group=None):
+    """Average a list of small tensors over the ranks IN PLACE through one flattened all-reduce (the batch-norm batch
+    statistics of a data-parallel training step: 15 layers x (mean, variance)).  No-op on one rank."""
+    if not tensors or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return tensors
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+    return tensors
