@@ -221,6 +221,63 @@ def dry_run_cpu(args, world, rank):
     return 0
 
 
+def train_bench(args, world, rank, device, backend):
+    """`--train`: RAFT.train_step (forward with tape, sequence_loss, backward through time, clip, AdamW) on synthetic data at
+    the reference's training crop (configs/train_chairs.yml: 368x496, iters 12), batch 4 per GPU; with N > 1 ranks every step
+    all-reduces the 5.26 M gradients (one bucket) and the batch-norm batch statistics over the job's backend.  Reported next
+    to the inference headline, never instead of it."""
+    import torch.distributed as dist
+    import tf_raft_amd
+    from tf_raft_amd import losses, training
+    from tf_raft_amd import weights as wm
+    B, Ht, Wt, iters = args.batch or 4, 368, 496, 12
+    rng = np.random.default_rng(100 + rank)
+    model = tf_raft_amd.RAFT(weights=wm.init_weights('raft', seed=0), iters=iters, iters_pred=24)
+    sched = training.CyclicalLearningRate(4e-4, 8e-4, 1000, training.first_cycle_scaler)
+    model.compile(optimizer=training.AdamW(1e-4, sched), clip_norm=1.0, loss=losses.sequence_loss, epe=losses.end_point_error,
+                  tape_dtype=args.tape)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(2000 + rank)
+    data = (torch.rand((B, Ht, Wt, 3), device=device, generator=gen) * 255.0, torch.rand((B, Ht, Wt, 3), device=device, generator=gen) * 255.0,
+            torch.randn((B, Ht, Wt, 2), device=device, generator=gen) * 3.0, torch.ones((B, Ht, Wt), device=device, dtype=torch.bool))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(1, args.warmup)):
+        res = model.train_step(data)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = model.train_step(data)
+    fence()
+    elapsed = time.perf_counter() - t0
+    seen = 1
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        seen = ranks_seen(dist, world, rank, device)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'training image-pairs/sec at 368x496 iters=12 (RAFT.train_step)', 'value': round(world * B * args.steps / elapsed, 3),
+            'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': max(1, args.warmup),
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.tape == 'f32' else 'f32 arithmetic, bf16 tape storage', 'data': 'synthetic', 'ranks_seen': seen,
+            'loss_last_step': float(res['loss']), 'peak_mem_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'config': {'workload': f'RAFT train_step, BASELINE configs[4] per-GPU shape: batch {B}/GPU {Ht}x{Wt} iters={iters}, AdamW + '
+                                   f'clip_by_global_norm, tape {args.tape}',
+                       'pairs_per_gpu': B, 'global_batch': world * B, 'parallelism': f'dp{world}',
+                       'collective': ('all_reduce(gradients, 21 MB in one bucket) + all_reduce(batch-norm statistics) over '
+                                      + ('RCCL' if backend == 'nccl' else backend)) if world > 1 else 'none'}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -230,6 +287,10 @@ def main():
                     help='image pairs per GPU per step (default: 4 on one GPU = BASELINE configs[1]; 8 per GPU on N > 1 '
                          'GPUs = configs[2], 64 pairs on 8 GPUs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--train', action='store_true',
+                    help='time RAFT.train_step instead (BASELINE configs[4] per-GPU shape: batch 4, 368x496, iters 12; gradients '
+                         'all-reduced over the job backend when --gpus N > 1); NOT the headline metric')
+    ap.add_argument('--tape', default='f32', choices=['f32', 'bf16'], help='--train: storage type of the activation tape')
     ap.add_argument('--cpu-runs', type=int, default=2)
     args = ap.parse_args()
 
@@ -257,6 +318,9 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.train:
+        return train_bench(args, world, rank, device, backend)
 
     import tf_raft_amd
     from tf_raft_amd import _dev, _ffi

@@ -74,6 +74,7 @@ class RAFT:
             weights = weights_mod.init_weights(self.variant, seed)     # Keras default initialisers
         weights_mod.check_weights(self.variant, weights)
         self._weights = dict(weights)
+        self._dw, self._host_stale, self._train_vars = None, False, None     # device master copies of train_step
         self._build(weights)
 
     def _build(self, weights):
