@@ -1,47 +1,58 @@
-"""Where a forward call spends its time, from a rocprofv3 --kernel-trace CSV of tools/graph_probe.py: the kernels of the LAST
-call (found as the last gap > 0.5 ms between kernels... the calls are separated by host synchronisation), their union
-busy time, the idle time between them, and how much of the time two or more kernels overlap.
+"""Where one forward call spends its time, from a rocprofv3 --kernel-trace CSV of tools/graph_probe.py.
+Calls are delimited by their first kernel (`enc_prep_kernel`: two per forward, the first one opens a call); the LAST complete
+call is analysed: wall time, union busy time, idle time, time with >= 2 kernels in flight -- for the whole call and for the
+prediction loop alone (from the first lookup kernel on) -- the idle-gap distribution, and which kernels ran on which queue.
 usage: python tools/graph_trace.py <kernel_trace.csv> [label]"""
 import csv
 import sys
+from collections import Counter
 
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '')))
 rows.sort()
-# split into calls at idle gaps > 300 us
-calls, cur, last_end = [], [], None
-for s, e, n, q in rows:
-    if last_end is not None and s - last_end > 300_000 and cur:
-        calls.append(cur)
-        cur = []
-    cur.append((s, e, n, q))
-    last_end = e if last_end is None else max(last_end, e)
-if cur:
-    calls.append(cur)
-call = max(calls[-3:], key=len) if len(calls) >= 3 else calls[-1]
-t0, t1 = call[0][0], max(e for _, e, _, _ in call)
-ev = sorted([(s, 1) for s, _, _, _ in call] + [(e, -1) for _, e, _, _ in call])
-busy = over = 0
-depth, prev = 0, t0
-for t, d in ev:
-    if depth >= 1:
-        busy += t - prev
-    if depth >= 2:
-        over += t - prev
-    depth += d
-    prev = t
 label = sys.argv[2] if len(sys.argv) > 2 else ''
-print(f'{label}: {len(calls)} calls in the trace; last call {len(call)} kernels on queues {sorted({q for *_, q in call})}: '
-      f'wall {(t1 - t0) / 1e6:.3f} ms, union busy {busy / 1e6:.3f} ms, idle {(t1 - t0 - busy) / 1e6:.3f} ms, '
-      f'>= 2 kernels in flight {over / 1e6:.3f} ms, sum of durations {sum(e - s for s, e, _, _ in call) / 1e6:.3f} ms')
-# the 8 largest idle gaps and what follows them
-gaps, end = [], call[0][1]
-for s, e, n, q in call[1:]:
-    if s > end:
-        gaps.append((s - end, n[:60]))
-    end = max(end, e)
-gaps.sort(reverse=True)
-print('  largest idle gaps (us, next kernel):', [(round(g / 1e3, 1), n) for g, n in gaps[:6]], ' total gaps', len(gaps),
-      ' median gap us', round(sorted(g for g, _ in gaps)[len(gaps) // 2] / 1e3, 2) if gaps else 0)
+starts = [i for i, r in enumerate(rows) if 'enc_prep_kernel' in r[2]][::2]
+if len(starts) < 2:
+    print(label, ': fewer than two calls in the trace')
+    sys.exit(0)
+call = rows[starts[-2]:starts[-1]]                      # the last COMPLETE call
+
+
+def stats(ks):
+    t0, t1 = ks[0][0], max(e for _, e, _, _ in ks)
+    ev = sorted([(s, 1) for s, _, _, _ in ks] + [(e, -1) for _, e, _, _ in ks])
+    busy = over = depth = 0
+    prev = t0
+    for t, d in ev:
+        if depth >= 1:
+            busy += t - prev
+        if depth >= 2:
+            over += t - prev
+        depth += d
+        prev = t
+    gaps, end = [], ks[0][1]
+    for s, e, n, q in ks[1:]:
+        if s > end:
+            gaps.append(s - end)
+        end = max(end, e)
+    gaps.sort()
+    return dict(wall=(t1 - t0) / 1e6, busy=busy / 1e6, idle=(t1 - t0 - busy) / 1e6, over=over / 1e6,
+                sum=sum(e - s for s, e, _, _ in ks) / 1e6, n=len(ks), gaps=len(gaps),
+                gap_med=gaps[len(gaps) // 2] / 1e3 if gaps else 0.0, gap_p90=gaps[int(len(gaps) * 0.9)] / 1e3 if gaps else 0.0,
+                gap_sum=sum(gaps) / 1e6)
+
+
+first_loop = next(i for i, r in enumerate(call) if 'lookup' in r[2])
+for name, ks in (('whole call', call), ('prediction loop', call[first_loop:])):
+    s = stats(ks)
+    print(f'{label} {name}: {s["n"]} kernels, wall {s["wall"]:.3f} ms, union busy {s["busy"]:.3f}, idle {s["idle"]:.3f} '
+          f'({s["gaps"]} gaps, median {s["gap_med"]:.2f} us, p90 {s["gap_p90"]:.2f} us), >= 2 kernels in flight {s["over"]:.3f} ms, '
+          f'sum of kernel durations {s["sum"]:.3f} ms')
+q = Counter((r[3], r[2].split('(')[0].replace('void ', '')[:40]) for r in call[first_loop:])
+by_queue = {}
+for (queue, kn), c in q.items():
+    by_queue.setdefault(queue, []).append(f'{kn} x{c}')
+for queue in sorted(by_queue):
+    print(f'  queue {queue}:', ', '.join(sorted(by_queue[queue]))[:600])
