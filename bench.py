@@ -65,7 +65,7 @@ def winograd_layers(pairs=4):
     from tf_raft_amd import _ffi
     m3 = int(_ffi.get_option('RAFT_CONV_WINO') or 13)
     m44 = _ffi.get_option('RAFT_CONV_WINO4')
-    m44 = int(m44) if m44 else (9 | (4 if pairs >= 8 else 0))
+    m44 = int(m44) if m44 else (0 if pairs < 4 else 9 | (4 if pairs >= 8 else 0))
     mg = int(_ffi.get_option('RAFT_GRU_WINO') or 15)
     mg4 = int(_ffi.get_option('RAFT_GRU_WINO4') or 15)
     on = {}

@@ -283,6 +283,23 @@ def test_north_star_free_running_final_prediction(variant, seed):
     assert _max_epe(_np(last), want[-1]) <= TOL
 
 
+def test_north_star_with_every_3x3_layer_on_winograd_f4x4(raft_opt):
+    """The F(4x4,3x3) kernels are the default from 4 pairs on (checked per element by test_north_star_benchmarked_batches); here
+    the single-pair north-star case is run with ALL THREE 3x3 layers of the update block forced onto them (RAFT_CONV_WINO4 = 13:
+    at this size the K-split workgroups), free-running, 24 iterations, 1e-3 on every prediction."""
+    import oracle
+    import tf_raft_amd
+    cond = _assert_oracle_is_well_conditioned('raft_448x512_seed0_it24_conditioned')
+    i1, i2, wts = _conditioned_case('raft', 448, 512, 0)
+    want = oracle.RAFT(wts, iters_pred=24)([i1, i2])
+    raft_opt.set('RAFT_CONV_WINO4', '13')
+    got = tf_raft_amd.RAFT(weights=wts, iters_pred=24)([i1, i2])
+    errs = [_max_epe(_np(g), w) for g, w in zip(got, want)]
+    report('north-star raft 448x512 seed 0, F(4x4,3x3) on convc2 / conv / fh1_mask0', final_epe=errs[-1], worst_epe=max(errs),
+           oracle32_vs_64_final=cond['epe32v64'][-1])
+    assert max(errs) <= TOL, errs
+
+
 def test_north_star_benchmarked_batches():
     """The benchmarked configurations: B=4 (BASELINE configs[1]) and B=8 (configs[2] per GPU) at 448x512, 24 iterations
     free-running.  Kernel / tile selection depends on B, so each batch element is compared with the oracle run on that

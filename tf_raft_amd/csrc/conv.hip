@@ -262,10 +262,15 @@ static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weig
 constexpr int RAFT_WINO_DEFAULT = 13;
 constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr, 4: gru_q, 8: fh1}, switch RAFT_SMALL_WINO
 // F(4x4, 3x3) (conv_wino4.h), switch RAFT_CONV_WINO4 = bit mask {1: convc2, 4: conv, 8: fh1_mask0 / fh1}.  Default (us alone,
-// F(4x4) against F(2x2), profiles/r07i_wino4_bench.txt): the flow / mask head (63 vs 91 at 4 pairs, 128 vs 169 at 8) and convc2
-// (61 vs 76 with the K-split workgroups, 107 vs 132) at every size; conv (N = 128) from 8 pairs on (65 vs 114; at 4 pairs its
-// 112 K-split workgroups lose to F(2x2): 59 vs 49).
-static int wino4_default_mask(const ConvArgs &a) { return 8 | 1 | ((int64_t)a.B * a.H * a.W >= 8 * 3584 ? 4 : 0); }
+// F(4x4) against F(2x2), profiles/r07i_wino4_bench.txt): from 4 pairs on the flow / mask head (63 vs 91 at 4 pairs, 128 vs 169 at
+// 8) and convc2 (61 vs 76 with the K-split workgroups, 107 vs 132); conv (N = 128) from 8 pairs on (65 vs 114; at 4 pairs its
+// 112 K-split workgroups lose to F(2x2): 59 vs 49).  Below 4 pairs nothing: a launch is then one round of workgroups whose
+// duration is one workgroup's K loop, and the one-wave-per-SIMD F(4x4) workgroup is the longer one (single pair: 151 pairs/s
+// without, 133 with -- same-box A/B with bench.py, profiles/r07p_bench_mask_ab.txt: 4 pairs 270 -> 282, 8 pairs 285 -> 296).
+static int wino4_default_mask(const ConvArgs &a) {
+    const int64_t m = (int64_t)a.B * a.H * a.W;
+    return m < 4 * 3584 ? 0 : (8 | 1 | (m >= 8 * 3584 ? 4 : 0));
+}
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
                           hipStream_t s, bool small = false, const raft_conv_weights *wino44 = nullptr) {
     const int mask = small ? raft_opt(RAFT_OPT_SMALL_WINO, RAFT_SMALL_WINO_DEFAULT) : raft_opt(RAFT_OPT_CONV_WINO, RAFT_WINO_DEFAULT);
@@ -739,7 +744,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         RAFT_TRY(launch_conv3x3(wts->fh1_mask0, wts->fh1_mask0_w, 8, a, EPI_RELU, s, false, &wts->fh1_mask0_w44));
         RAFT_MARK();
     } else {           // relu(flow_head.conv1(net)) only            3x3, 128 -> 256        -> fm[:, 0:256]
-        const bool w44 = wts->fh1_w44.wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, 8) & 8);
+        const bool w44 = wts->fh1_w44.wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, (int64_t)B * h * w < 4 * 3584 ? 0 : 8) & 8);
         ConvArgs a = conv_args(w44 ? wts->fh1_w44 : wts->fh1_w, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 256, fm, 512);
         RAFT_TRY(w44 ? raft_launch_conv_wino4(a, EPI_RELU, s, wts->fh1_mask0_w44.npad) : raft_launch_conv_wino(a, EPI_RELU, s));
     }
