@@ -44,6 +44,7 @@
  *   RAFT_ENC_TILE       "<th><tn>" halo tile of the encoder convolutions, e.g. 72                (default: by map height)
  *   RAFT_ENC_WINO       0/1  encoder ResBlock 3x3 layers on the F(2x2,3x3) kernel                 (default 1)
  *   RAFT_LOOKUP_FUSED   0/1  prediction loops: lookup + convc1 as two kernels / fused (raft_lookup_convc1_f32)  (default 1)
+ *   RAFT_MASK_FUSED     0/1  prediction loops: mask.2 + convex upsampling as two kernels / one (the mask is never stored) (default 1)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)

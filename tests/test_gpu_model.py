@@ -603,3 +603,25 @@ def test_fused_lookup_loop_matches_two_kernel_loop(raft_opt):
     report('fused vs two-kernel lookup loop', worst_epe=max(errs))
     assert max(errs) <= 1e-4
     assert any(not np.array_equal(a, b) for a, b in zip(fused, two))      # the switch did change the kernels
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 192), (1, 72, 104), (4, 448, 512)])     # exact tiles; ragged 9 x 13 maps; the benchmarked shape
+def test_fused_mask_upsample_is_bitwise_the_two_kernel_path(shape, raft_opt):
+    """RAFT_MASK_FUSED (default on): mask.2 and RAFT.upsample_flow run as ONE kernel that never stores the (B, h, w, 576) mask
+    (csrc/mask_upsample.hip).  It keeps the K order of the direct 1x1 kernel and the softmax / blend arithmetic of the upsampling
+    kernel, so every prediction of every loop (all-predictions, single-stream, final-only) is bit for bit the two-kernel one."""
+    import tf_raft_amd
+    B, H, W = shape
+    i1, i2, wts = _conditioned_case('raft', H, W, 2, B=B)
+    iters = 4 if H >= 448 else 6
+    fused, two = {}, {}
+    for opt, res in (('1', fused), ('0', two)):
+        raft_opt.set('RAFT_MASK_FUSED', opt)
+        model = tf_raft_amd.RAFT(weights=wts, iters_pred=iters)
+        res['overlap'] = [_np(p) for p in model([i1, i2])]
+        res['final'] = _np(model.predict_step((i1, i2)))
+        res['single'] = [_np(p) for p in tf_raft_amd.RAFT(weights=wts, iters_pred=iters, overlap=False)([i1, i2])]
+    for a, b_ in zip(fused['overlap'] + fused['single'] + [fused['final']], two['overlap'] + two['single'] + [two['final']]):
+        np.testing.assert_array_equal(a, b_)
+    assert np.isfinite(fused['final']).all() and float(np.abs(fused['final']).max()) > 0
+    report(f'fused mask.2 + upsampling {shape}', predictions_compared=len(fused['overlap']) + len(fused['single']) + 1)

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libraft_hip.so')
 SOURCES = ['corr.hip', 'upsample.hip', 'conv.hip', 'conv_halo_11.hip', 'conv_halo_33.hip', 'conv_halo_15.hip',
-           'conv_halo_51.hip', 'encoder.hip', 'ondemand.hip', 'host_util.hip', 'conv_wino.hip', 'conv_wino1d.hip', 'conv_wino4.hip', 'metrics.hip', 'backward.hip']
+           'conv_halo_51.hip', 'encoder.hip', 'ondemand.hip', 'host_util.hip', 'conv_wino.hip', 'conv_wino1d.hip', 'conv_wino4.hip', 'mask_upsample.hip', 'metrics.hip', 'backward.hip']
 HEADERS = ['common.h', 'conv_mfma.h', 'conv_halo.h', 'conv_wino.h', 'conv_wino1d.h', 'conv_wino4.h', 'lookup_common.h', os.path.join('..', '..', 'include', 'raft_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on',
          '-Wall', '-Wno-unused-function']

@@ -9,6 +9,14 @@
 #include "conv_wino1d.h"
 #include "conv_wino4.h"
 
+// mask.2 + RAFT.upsample_flow in one kernel (mask_upsample.hip)
+int raft_launch_mask_upsample(const float *a, int lda, const float *wp, const float *bias, int npad, const float *flow, int B,
+                              int h, int w, float scale, float *out, hipStream_t s);
+// RAFT_MASK_FUSED (default 1): the prediction loops run mask.2 and the convex upsampling as one kernel
+static bool mask_is_fused(const raft_basic_update_weights *wts) {
+    return raft_opt(RAFT_OPT_MASK_FUSED, 1) != 0 && wts->mask2.wp != nullptr && wts->mask2.npad == 576;
+}
+
 // ------------------------------------------------------------------------------------------------
 // tile selection + dispatch of the implicit-GEMM kernel
 // ------------------------------------------------------------------------------------------------
@@ -665,7 +673,7 @@ static bool lookup_is_fused(const raft_basic_update_weights *wts, const LookupSo
 // fused_src != NULL: st->corr is NOT read; cor1 comes from the volume through the fused kernel
 static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h, int w, const raft_state *st,
                              void *stream, StageTimer *tm, Overlap *ov = nullptr, bool with_mask = true,
-                             const LookupSource *fused_src = nullptr) {
+                             const LookupSource *fused_src = nullptr, float *flow_up_fused = nullptr) {
     RAFT_REQUIRE_PTR(wts);
     RAFT_TRY(check_state(st));
     RAFT_REQUIRE(B > 0 && h > 0 && w > 0, RAFT_E_SHAPE);
@@ -759,7 +767,14 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         RAFT_MARK();
     }
     if (ov) RAFT_HIP(hipEventRecord(ov->e_fh, s));
-    if (with_mask) {   // mask = 0.25 * mask.2(.)             1x1, 256 -> 576
+    if (with_mask && flow_up_fused != nullptr) {
+        // mask.2 and the convex upsampling as ONE kernel (mask_upsample.hip): the mask is never written.  Besides fm (the mask
+        // branch already waits for fh1_mask0) it needs the flow fh2 has just written.
+        if (ov) RAFT_HIP(hipStreamWaitEvent(sm, ov->e_fh, 0));
+        RAFT_TRY(raft_launch_mask_upsample(fm + 256, 512, wts->mask2.wp, wts->mask2.bias, wts->mask2.npad, st->flow, B, h, w,
+                                           0.25f, flow_up_fused, sm));
+        RAFT_MARK();
+    } else if (with_mask) {   // mask = 0.25 * mask.2(.)             1x1, 256 -> 576
         ConvArgs a = conv_args(wts->mask2, fm + 256, 512, 256, nullptr, 0, 0, B, h, w, 576, st->mask, 576);
         a.scale = 0.25f;
         RAFT_TRY(raft_launch_conv(a, 1, 1, EPI_LINEAR, sm));
@@ -787,8 +802,9 @@ extern "C" int raft_iterate_basic_f32(const raft_basic_update_weights *wts, cons
     const bool fused = lookup_is_fused(wts, &src);
     for (int i = 0; i < iters; ++i) {
         if (!fused) RAFT_TRY(raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream));
-        RAFT_TRY(update_basic_impl(wts, B, h, w, st, stream, nullptr, nullptr, true, fused ? &src : nullptr));
-        RAFT_TRY(raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream));
+        const bool mf = mask_is_fused(wts);
+        RAFT_TRY(update_basic_impl(wts, B, h, w, st, stream, nullptr, nullptr, true, fused ? &src : nullptr, mf ? flow_up + i * up : nullptr));
+        if (!mf) RAFT_TRY(raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream));
     }
     return RAFT_OK;
 }
@@ -909,11 +925,15 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
         const bool with_mask = !final_only || i == iters - 1;
         const bool fused = lookup_is_fused(wts, &src);
         rc = fused ? RAFT_OK : loop_lookup(src, st, B, h, w, stream);
-        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov, with_mask, fused ? &src : nullptr);
+        float *up_i = flow_up + (final_only ? 0 : i * up);
+        const bool mf = with_mask && mask_is_fused(wts);
+        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov, with_mask, fused ? &src : nullptr, mf ? up_i : nullptr);
         if (!with_mask) continue;
-        // upsample on the mask branch: needs mask2 (same stream) and the flow written by fh2
-        if (rc == RAFT_OK) rc = (int)hipStreamWaitEvent(ov.s2, ov.e_fh, 0);
-        if (rc == RAFT_OK) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + (final_only ? 0 : i * up), ov.s2);
+        if (!mf) {
+            // upsample on the mask branch: needs mask2 (same stream) and the flow written by fh2
+            if (rc == RAFT_OK) rc = (int)hipStreamWaitEvent(ov.s2, ov.e_fh, 0);
+            if (rc == RAFT_OK) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, up_i, ov.s2);
+        }
         if (rc == RAFT_OK) rc = (int)hipEventRecord(ov.e_up, ov.s2);
         ov.have_up = true;
     }
@@ -1042,8 +1062,10 @@ extern "C" int raft_iterate_basic_timed_f32(const raft_basic_update_weights *wts
         // RAFT_LOOKUP_FUSED as in the product loops: fused, the lookup stage is empty and the convc1 stage is the fused kernel
         if (!fused) rc = raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream);
         tm.mark(s);
-        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, &tm, nullptr, true, fused ? &src : nullptr);
-        if (rc == RAFT_OK) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream);
+        // RAFT_MASK_FUSED likewise: fused, the mask2 stage is the fused kernel and the upsampling stage is empty
+        const bool mf = mask_is_fused(wts);
+        if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, &tm, nullptr, true, fused ? &src : nullptr, mf ? flow_up + i * up : nullptr);
+        if (rc == RAFT_OK && !mf) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream);
         tm.mark(s);
     }
     if (rc == RAFT_OK) rc = (int)hipStreamSynchronize(s);
