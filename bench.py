@@ -486,6 +486,7 @@ def main():
         # per-kernel numbers come from the TWO-kernel path (stand-alone lookup, stand-alone convc1: the kernels the
         # roofline entries name); the product loop runs them fused (RAFT_LOOKUP_FUSED, default on), timed separately
         _ffi.set_option('RAFT_LOOKUP_FUSED', 0)
+        _ffi.set_option('RAFT_MASK_FUSED', 0)                 # likewise mask.2 and the upsampling (RAFT_MASK_FUSED, default on)
         per_launch_ms = timed_replay()
         # What an event bracket adds to every stage: the SAME single-stream launches without events in between
         # (raft_iterate_basic_f32), timed with one event pair, against the sum of the 14 bracketed stages.  An event record
@@ -505,6 +506,7 @@ def main():
         plain_iter_ms = float(np.median(plain[1:]))
         bracket_ms = max(0.0, (float(per_launch_ms.sum()) - plain_iter_ms) / len(STAGES))
         _ffi.set_option('RAFT_LOOKUP_FUSED', None)
+        _ffi.set_option('RAFT_MASK_FUSED', None)
         fused_ms = timed_replay()
         stage_ms_events = {k: round(float(v), 5) for k, v in zip(STAGES, per_launch_ms)}
         stage_ms = {k: round(max(float(v) - bracket_ms, 1e-6), 5) for k, v in zip(STAGES, per_launch_ms)}
@@ -565,6 +567,18 @@ def main():
             'two_kernels_us_per_launch': round(two_us, 2), 'standalone_convc1_us': round(stage_ms['convc1'] * 1e3, 2),
             'estimated_incremental_lookup_us': round(inc_us, 2),
             'note': 'fused kernel time minus stand-alone convc1 time: a model, not a measured kernel duration'}
+        # mask.2 + upsampling as the product loop runs them (one kernel, the mask never stored): the mask2 stage holds the fused
+        # kernel, the upsample stage is an empty bracket
+        im, iu = STAGES.index('mask2'), STAGES.index('upsample_convex')
+        mu_us = max(float(fused_ms[im] + fused_ms[iu] - 2 * bracket_ms), 1e-3) * 1e3
+        mu_bytes = bytes_['upsample_convex'] - 4.0 * B * h * w * 576 + 4.0 * B * h * w * 256     # no mask read; mask.0's output read
+        result['mask_upsample_fused'] = {
+            'kernel': 'mask.2 + convex upsampling (mask_upsample_kernel)', 'us_per_launch': round(mu_us, 2),
+            'two_kernels_us_per_launch': round(float(stage_ms['mask2'] + stage_ms['upsample_convex']) * 1e3, 2),
+            'flops_per_launch': flops['mask2'], 'achieved_tflops': round(flops['mask2'] / (mu_us * 1e-6) / 1e12, 2),
+            'frac_of_fp32_mfma_peak': round(flops['mask2'] / (mu_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            'hbm_bytes_per_launch': mu_bytes, 'hbm_gbs': round(mu_bytes / (mu_us * 1e-6) / 1e9, 1),
+            'mask_bytes_not_moved': 8.0 * B * h * w * 576}
         # The same stand-alone kernel in the single-stream loop at 8 pairs (BASELINE configs[2] per GPU): a 550 MB volume,
         # larger than the 256 MiB Infinity Cache, which the 275 MB volume of 4 pairs is not (SURVEY 8d asks for B >= 8).
         if world == 1 and B != 8:
@@ -576,6 +590,7 @@ def main():
             st8 = model._get_state(8, h, w, device)
             up8 = torch.empty((ITERS, 8, H, W, 2), device=device)
             _ffi.set_option('RAFT_LOOKUP_FUSED', 0)
+            _ffi.set_option('RAFT_MASK_FUSED', 0)
             buf = (C.c_float * len(STAGES))()
             acc8 = np.zeros(len(STAGES))
             for _ in range(2):
@@ -585,6 +600,7 @@ def main():
                     _dev.ptr(up8), _dev.stream_ptr(), buf), 'iterate_basic_timed')
                 acc8 += np.array(list(buf))
             _ffi.set_option('RAFT_LOOKUP_FUSED', None)
+            _ffi.set_option('RAFT_MASK_FUSED', None)
             l8_ms = max(float(acc8[0]) / (2 * ITERS) - bracket_ms, 1e-6)
             b8 = stage_work(8, h, w)[1]['corr_lookup']
             tr8, _ = pmc_traffic('corr_lookup', 8)

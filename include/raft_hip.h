@@ -43,6 +43,8 @@
  *                            launches of fewer wave-tasks than SIMDs, i.e. single pairs)
  *   RAFT_ENC_TILE       "<th><tn>" halo tile of the encoder convolutions, e.g. 72                (default: by map height)
  *   RAFT_ENC_WINO       0/1  encoder ResBlock 3x3 layers on the F(2x2,3x3) kernel                 (default 1)
+ *   RAFT_ENC_WINO4      bit mask {1 layer1, 2 layer2, 4 layer3}: stride-1 3x3 layers of those encoder stages on the
+ *                       F(4x4,3x3) kernel where a transformed copy is present (block_w44)      (default: every stage whose launch has >= 100 workgroups)
  *   RAFT_LOOKUP_FUSED   0/1  prediction loops: lookup + convc1 as two kernels / fused (raft_lookup_convc1_f32)  (default 1)
  *   RAFT_MASK_FUSED     0/1  prediction loops: mask.2 + convex upsampling as two kernels / one (the mask is never stored) (default 1)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
@@ -61,7 +63,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 211          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 212          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -378,6 +380,9 @@ typedef struct raft_encoder_weights {
     /* optional (wp == NULL: absent): Winograd F(2x2, 3x3) transformed copies of block[i][0] (when it has
      * stride 1) and block[i][1], packed as 4x4-tap kernels (see raft_conv2d_winograd_f32) */
     raft_conv_weights block_w[6][2];
+    /* optional: Winograd F(4x4, 3x3) transformed copies of the same layers in the consumption order of
+     * raft_conv2d_winograd4_f32 (used for the stages RAFT_ENC_WINO4 selects) */
+    raft_conv_weights block_w44[6][2];
 } raft_encoder_weights;
 
 int64_t raft_encoder_workspace_floats(const raft_encoder_weights *w, int n, int H, int W);

@@ -216,6 +216,35 @@ def test_encoders_match_oracle(variant, H, W, B):
     del oracle
 
 
+@pytest.mark.parametrize('H,W,B', [(128, 160, 2), (200, 264, 1), (448, 512, 4)])     # exact, ragged (100 x 132 maps), benchmarked
+def test_encoder_winograd_f4x4_stages_match_oracle(H, W, B, raft_opt):
+    """RAFT_ENC_WINO4: the stride-1 3x3 layers of the selected encoder stages on the F(4x4, 3x3) kernel -- fnet through its
+    instance-norm variants (moments in the epilogue, the producer's normalisation + relu applied while the halo tile is staged),
+    cnet through the relu / residual epilogues.  Every mask stays within the encoder bound against the float64 oracle, and the
+    default (layer1) is reported against F(2x2) everywhere."""
+    import oracle
+    from oracle.layers import W as OW, encoder
+    import tf_raft_amd
+    from tf_raft_amd import weights as wm
+    wts = wm.init_weights('raft', seed=5, perturb=True)
+    i1, i2 = _images(2, B, H, W)
+    x1 = torch.as_tensor(2 * (i1 / 255.0) - 1.0)
+    x2 = torch.as_tensor(2 * (i2 / 255.0) - 1.0)
+    ow = OW(wts, torch.float64)
+    r1, r2 = encoder(ow, 'fnet', [x1.double(), x2.double()])
+    rc = encoder(ow, 'cnet', x1.double())
+    errs = {}
+    for mask in ('0', '1', '7'):
+        raft_opt.set('RAFT_ENC_WINO4', mask)
+        model = tf_raft_amd.RAFT(weights=wts, iters_pred=1)
+        f1, f2 = model.fnet([x1, x2])
+        c = model.cnet(x1)
+        errs[mask] = [float(np.abs(_np(g) - r.numpy()).max()) / max(1.0, float(r.abs().max())) for g, r in ((f1, r1), (f2, r2), (c, rc))]
+        assert max(errs[mask]) < 1e-4, (mask, errs[mask])
+    report(f'encoder F(4x4) stages {H}x{W} B={B}', f2x2=max(errs['0']), layer1=max(errs['1']), all_stages=max(errs['7']))
+    del oracle
+
+
 # ------------------------------------------------------------------ free-running parity, small sizes
 @pytest.mark.parametrize('variant,H,W,iters,seed', [
     ('raft', 64, 96, 12, 0), ('raft', 128, 160, 12, 1), ('small', 64, 96, 12, 0), ('small', 256, 256, 4, 0)])

@@ -186,13 +186,17 @@ def test_pack_encoder_folds_batch_norm_and_covers_every_layer(rng):
     convs, norms, dims = packing.pack_encoder(wts, 'cnet', 'batch')
     assert dims == (64, 64, 96, 128, 256) and norms == []
     fields = [f for f, *_ in convs]
-    direct = [f for f in fields if not (isinstance(f, tuple) and f[0] == 'block_w')]
+    direct = [f for f in fields if not (isinstance(f, tuple) and f[0] in ('block_w', 'block_w44'))]
     assert direct[0] == 'conv1' and direct[-1] == 'conv2' and len(direct) == 1 + 6 * 2 + 2 + 1
     assert ('block', 2, 2) in fields and ('block', 4, 2) in fields and ('block', 0, 2) not in fields
     # Winograd copies: every stride-1 3x3 convolution (all conv2, and conv1 of the blocks without a down-sampling branch)
     wino = sorted(f for f in fields if isinstance(f, tuple) and f[0] == 'block_w')
     assert wino == sorted([('block_w', b, 1) for b in range(6)] + [('block_w', b, 0) for b in (0, 1, 3, 5)])
+    wino4 = sorted(f for f in fields if isinstance(f, tuple) and f[0] == 'block_w44')
+    assert wino4 == sorted([('block_w44', b, 1) for b in range(6)] + [('block_w44', b, 0) for b in (0, 1, 3, 5)])
     by_field = {f: (wp, bb, npad) for f, wp, bb, npad in convs}
+    wp4, _, npad4 = by_field[('block_w44', 0, 1)]                      # F(4x4): (Cin/16, 72 slots, 4, npad/32, 16, 2, 2)
+    assert wp4.shape == (4, 72, 4, 2, 16, 2, 2) and npad4 == 64
     wp_w, _, npad_w = by_field[('block_w', 3, 1)]
     assert wp_w.shape == (16, 96 // 4, npad_w, 4) and npad_w == 128
     # U = G g G^T: the four corner taps are the corner kernel entries, and summing U over taps reproduces sum(g) * 2.25

@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 211     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 212     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -42,7 +42,7 @@ class SmallUpdateWeights(C.Structure):
 class EncoderWeights(C.Structure):
     _fields_ = [('c0', C.c_int), ('c1', C.c_int), ('c2', C.c_int), ('c3', C.c_int), ('cout', C.c_int),
                 ('norm', C.c_int), ('conv1', ConvWeights), ('block', (ConvWeights * 3) * 6), ('conv2', ConvWeights),
-                ('in_gamma', C.c_void_p * 19), ('in_beta', C.c_void_p * 19), ('block_w', (ConvWeights * 2) * 6)]
+                ('in_gamma', C.c_void_p * 19), ('in_beta', C.c_void_p * 19), ('block_w', (ConvWeights * 2) * 6), ('block_w44', (ConvWeights * 2) * 6)]
 
 
 NORM_NONE, NORM_INSTANCE, NORM_FOLDED = 0, 1, 2

@@ -115,11 +115,16 @@ __device__ __forceinline__ constexpr int tap_row(int ph, int row) { return ph ==
 // KS = 2: workgroup = 1 row block (4 x 64 pixels) x 64 channels, wave = (pair of column blocks, K half): wave set ks walks the
 // 16-channel chunks ks, ks + 2, ... (a stage = two chunks, staged side by side) and the two partial results meet in LDS after the
 // output transform -- for layers whose 2-row-block workgroups are too few to cover the chip (N <= 256 at 4 pairs).
-template <int EPI, int KS = 1>
+// PRE / STATS serve the instance-norm encoder as in conv_wino.h (KS = 1, one source): PRE applies relu(x * scale[b][c] + shift[b][c])
+// to every in-image element while the halo tile is written to LDS (the normalisation + relu of the producer: the normalised
+// tensor is never materialised; padding stays zero), STATS writes per-(workgroup, row block) (sum, sum of squares) of the raw
+// output per channel to p.stats[2 * pixel tile + rb][npad][2].
+template <int EPI, int KS = 1, int PRE = 0, int STATS = 0>
 __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     using namespace wino4;
     static_assert(EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_RES, "winograd F(4x4) kernel: linear / relu / residual epilogues");
     static_assert(KS == 1 || KS == 2, "K split: 1 or 2");
+    static_assert((!PRE && !STATS) || KS == 1, "encoder variants: two row blocks per workgroup");
     constexpr int TH = KS == 1 ? 8 : 4, HH = TH + 2, HP = HH * HWP;   // halo rows x 66 pixels
     constexpr int A_BUF = HH * RS + 16;                               // + one dummy pixel for the padding items of the staging loop
     constexpr int NA = (HP * 4 * KS + NTHR - 1) / NTHR;               // 16-byte items per thread per stage (11 / 13)
@@ -173,6 +178,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     // channel offset goes into the instruction's scalar offset, so a load is one instruction and no address arithmetic.
     unsigned pixoff[NA];
     int lds_off[NA], pixi[NA];
+    unsigned okbits = 0;                                               // PRE: bit i = item i lies inside the image
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int item = tid + NTHR * i;
@@ -182,10 +188,12 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
         const bool ok = (s2 < KS) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
         pixi[i] = ok ? (b * p.H + yy) * p.W + xx : -1;
+        okbits |= ok ? 1u << i : 0u;
         pixoff[i] = ok ? (unsigned)((pixi[i] * p.lda0 + s2 * 16 + c4 * 4) * 4) : RAFT_OOB;
         lds_off[i] = s2 < KS ? s2 * A_BUF + hy * RS + hx * 16 + (hx >> 2) * 4 + 2 * c4 : HH * RS;   // floats; second half at + 8
     }
     f32x4 ra[NA];
+    f32x2 pre_sc[2], pre_sh[2];                                        // PRE: scale / shift of the NEXT chunk's channel quad (tid & 3)
     // source of a chunk (channels [0, c0) come from a0, the rest from a1): descriptor and scalar channel offset of the NEXT
     // chunk are set once per chunk; at the switch from a0 to a1 the per-thread offsets are re-derived with a1's pixel stride
     __amdgpu_buffer_rsrc_t rsn = rs0;
@@ -198,6 +206,15 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
         const int ext = first ? (int)((((long)M - 1) * p.lda0 + p.c0) * 4) : (p.c1 ? (int)((((long)M - 1) * p.lda1 + p.c1) * 4) : 0);
         rsn = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? ext : 0, 0x00020000);   // past the last chunk: empty
         soff_n = (first ? ch : ch - p.c0) * 4;
+        if constexpr (PRE) {        // one source (the launcher checks): channel ch + 4 (tid & 3) of image b; past the last chunk: unused
+            const int cq = (st < nst ? ch : 0) + (tid & 3) * 4;
+            const f32x4 sc = *(const f32x4 *)(p.pre_scale + (long)b * cin + cq), sh = *(const f32x4 *)(p.pre_shift + (long)b * cin + cq);
+            pre_sc[0] = f32x2{sc[0], sc[1]};
+            pre_sc[1] = f32x2{sc[2], sc[3]};
+            pre_sh[0] = f32x2{sh[0], sh[1]};
+            pre_sh[1] = f32x2{sh[2], sh[3]};
+            return;
+        }
         if (on_first && !first) {   // wave-uniform, taken once
             on_first = false;
 #pragma unroll
@@ -210,8 +227,17 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     };
     auto lstore_item = [&](int i, int buf) {
         float *dst = smem + buf * (KS * A_BUF) + lds_off[i];
-        *(f32x2 *)dst = f32x2{ra[i][0], ra[i][1]};
-        *(f32x2 *)(dst + 8) = f32x2{ra[i][2], ra[i][3]};
+        f32x2 lo = f32x2{ra[i][0], ra[i][1]}, hi = f32x2{ra[i][2], ra[i][3]};
+        if constexpr (PRE) {
+            const bool ok = (okbits >> i) & 1u;
+            const f32x2 zero = f32x2{0.f, 0.f};
+            lo = __builtin_elementwise_max(__builtin_elementwise_fma(lo, pre_sc[0], pre_sh[0]), zero);
+            hi = __builtin_elementwise_max(__builtin_elementwise_fma(hi, pre_sc[1], pre_sh[1]), zero);
+            lo = ok ? lo : zero;
+            hi = ok ? hi : zero;
+        }
+        *(f32x2 *)dst = lo;
+        *(f32x2 *)(dst + 8) = hi;
     };
 
     // ---- fragments
@@ -448,6 +474,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
     // rows of two tiles (registers 2 rh, 2 rh + 1 of the accumulators): bias, activation / residual, stores.  Element (r, jx) =
     // pixel xb + 4 r + jx: wave-uniform byte offset from the lane base; tiles cut by the image border (`interior` false,
     // wave-uniform) add the per-element out-of-range bit.  i = index into bo / be / rowok (compile-time at every call site).
+    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};                     // STATS: (sum, sum of squares) of the lane's outputs per column block
     auto emit = [&](int j, int i, int rh, const f32x2 *Y) {
         const float bias = bias2[j];
         const unsigned vo = nok2[j] ? bo[i] + nofs[j] : RAFT_OOB, ve = (HAS_E0 && nok2[j]) ? be[i] + nofs[j] : RAFT_OOB;
@@ -473,6 +500,15 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
                 }
                 if ((RAFT_WINO4_ABL & 8) && v != 12345.678f) continue;
                 const unsigned dead = (interior | (rowok[i] & (xb + 4 * r + jx < p.W))) ? 0u : RAFT_OOB;
+                if constexpr (STATS) {
+                    // masked as DATA (0x80000000 -> all ones): reusing the lane condition behind `dead` keeps 32 of them alive in
+                    // SGPR pairs across the column block (61 spilled SGPRs)
+                    unsigned dd = dead;
+                    asm volatile("" : "+v"(dd));
+                    const float vs = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & ~(unsigned)((int)dd >> 31));
+                    st1[j] += vs;
+                    st2[j] = fmaf(vs, vs, st2[j]);
+                }
                 bstore(v, ro0, vo | dead, (4 * r + jx) * p.ldo0 * 4);
             }
         }
@@ -537,10 +573,24 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
             }
         }
     });
+    if constexpr (STATS) {   // lanes LR, LR + 16, LR + 32, LR + 48 hold the same channel; entry = (pixel tile, row block)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float s1 = st1[j], s2 = st2[j];
+            s1 += __shfl_xor(s1, 16, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const int n = n0 + (cb_e * 2 + j) * 16 + LR_e;
+            if (G_e == 0) *(float2 *)(p.stats + ((long)(2 * mt + rb_e) * p.npad + n) * 2) = make_float2(s1, s2);
+        }
+    }
 }
 
 #pragma clang diagnostic pop
 
 // launcher (conv_wino4.hip); `a.wp` holds the F(4x4, 3x3)-transformed weights in consumption order
-// (Cin/16, 72, 4, npad/32, 16, 2, 2) -- tf_raft_amd/packing.py pack_conv_winograd4.  epi: EPI_LINEAR / EPI_RELU / EPI_RES.
+// (Cin/16, 72, 4, npad/32, 16, 2, 2) -- tf_raft_amd/packing.py pack_conv_winograd4.  epi: EPI_LINEAR / EPI_RELU / EPI_RES;
+// a.stats != NULL (with EPI_LINEAR) selects STATS, a.pre_scale != NULL PRE on top of it (the instance-norm encoder's
+// combinations; one source, two-row-block workgroups).  Stats entries per image: 2 * ceil(H/8) * ceil(W/64).
 int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide_npad = 0);

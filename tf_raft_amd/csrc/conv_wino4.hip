@@ -5,7 +5,9 @@ int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide
     if (a.c0 <= 0 || a.c0 % 16 || a.c1 < 0 || a.c1 % 16 || a.npad <= 0 || a.npad % 64) return RAFT_E_UNSUPPORTED;
     if (a.lda0 % 4 || (a.c1 && a.lda1 % 4)) return RAFT_E_ALIGN;
     if (!raft_aligned16(a.a0) || !raft_aligned16(a.wp) || (a.c1 && !raft_aligned16(a.a1))) return RAFT_E_ALIGN;
-    if (a.init || a.pre_scale || a.stats || (a.Hi && (a.Hi != a.H || a.Wi != a.W))) return RAFT_E_UNSUPPORTED;
+    if (a.init || (a.Hi && (a.Hi != a.H || a.Wi != a.W))) return RAFT_E_UNSUPPORTED;
+    if ((a.pre_scale || a.stats) && (epi != EPI_LINEAR || a.stats == nullptr || a.c1 != 0)) return RAFT_E_UNSUPPORTED;
+    if (a.pre_scale && a.pre_shift == nullptr) return RAFT_E_NULL;
     if (epi == EPI_RES && a.e0 == nullptr) return RAFT_E_NULL;
     {   // 32-bit buffer offsets: every operand must span < 2 GiB
         const int64_t M = (int64_t)a.B * a.H * a.W, lim = (int64_t)1 << 31;
@@ -24,7 +26,14 @@ int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide
     const int grid_decide = decide_npad > 0 ? grid1 / nt * (decide_npad / 64) : grid1;
     const bool ks2_ok = (a.c0 % 32 == 0) && (a.c1 % 32 == 0);
     int ks = raft_opt(RAFT_OPT_WINO4_KS, grid_decide < 128 ? 2 : 1);
-    if (ks != 2 || !ks2_ok) ks = 1;
+    if (ks != 2 || !ks2_ok || a.stats) ks = 1;
+    if (a.stats) {   // instance-norm encoder: moments of the raw output, optionally the producer's normalisation + relu on the input
+        if (a.pre_scale)
+            conv_wino4_kernel<EPI_LINEAR, 1, 1, 1><<<grid1, 256, 0, s>>>(a);
+        else
+            conv_wino4_kernel<EPI_LINEAR, 1, 0, 1><<<grid1, 256, 0, s>>>(a);
+        return raft_launch_status();
+    }
     if (ks == 2) {
         const int grid = a.B * ((a.H + 3) / 4) * ((a.W + 63) / 64) * nt;
         if (epi == EPI_LINEAR)

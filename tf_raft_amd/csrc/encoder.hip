@@ -16,6 +16,9 @@
 #include "conv_halo.h"
 #include "conv_wino.h"
 
+// F(4x4, 3x3) launcher (conv_wino4.hip; the kernel header is not needed here)
+int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide_npad = 0);
+
 namespace {
 
 // ---------------------------------------------------------------- small kernels
@@ -228,6 +231,14 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
         if (tiles_w > tiles_max) tiles_max = tiles_w;
     }
     const bool use_wino = raft_opt(RAFT_OPT_ENC_WINO, 1) != 0;   // 0: direct 3x3 kernels everywhere (A/B timing, parity tests)
+    // stages whose stride-1 3x3 layers run the F(4x4, 3x3) kernel (bit 0 = layer1 ...).  Default: every stage whose launch has
+    // at least 100 of the kernel's 8 x 64-pixel x 64-channel workgroups -- at 4 pairs everything but cnet's layer3 (56).  Per
+    // kernel at 4 pairs (profiles/r07u_encoder_kernels_b4.txt): fnet's ten layers 1308 -> 1120 us, the 64-channel half-resolution
+    // layers ~190 -> ~150 us each (K = 64 is only four 16-channel chunks: prologue and output transform are 40 % of a workgroup);
+    // a layer3 launch with the K-split variant is slower than F(2x2) (41 against 28 us).  An explicit RAFT_ENC_WINO4 is
+    // taken as given.
+    const int wino4_mask = use_wino ? raft_opt(RAFT_OPT_ENC_WINO4, 7) : 0;
+    const bool wino4_forced = raft_opt_is_set(RAFT_OPT_ENC_WINO4);
     EncBufs b;
     float *p = workspace;
     b.img4 = p; p += align4((int64_t)n * H * W * 4);
@@ -254,9 +265,10 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
     auto conv = [&](EncKind kind, const raft_conv_weights &cw_direct, const float *in, int cin, int Hi, int Wi, int Ho, int Wo,
                     int pt, int pl, int cout, int epi, float *dst, const float *res, const float *pre_sc,
                     const float *pre_sh, int slot, const float *gamma, const float *beta,
-                    const raft_conv_weights *cw_wino = nullptr) -> int {
-        const bool wino = use_wino && kind == ENC_3x3_S1 && cw_wino && cw_wino->wp != nullptr;
-        const raft_conv_weights &cw = wino ? *cw_wino : cw_direct;
+                    const raft_conv_weights *cw_wino = nullptr, const raft_conv_weights *cw_wino4 = nullptr) -> int {
+        const bool wino4 = kind == ENC_3x3_S1 && cw_wino4 && cw_wino4->wp != nullptr && cin % 16 == 0;
+        const bool wino = !wino4 && use_wino && kind == ENC_3x3_S1 && cw_wino && cw_wino->wp != nullptr;
+        const raft_conv_weights &cw = wino4 ? *cw_wino4 : (wino ? *cw_wino : cw_direct);
         ConvArgs a = {};
         a.a0 = in; a.lda0 = (kind == ENC_STEM) ? 4 : cin; a.c0 = (kind == ENC_STEM) ? 7 * 32 : cin;
         a.wp = cw.wp; a.bias = cw.bias; a.npad = cw.npad; a.nvalid = cout;
@@ -267,10 +279,12 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
         a.stats = (inorm && slot >= 0) ? b.part : nullptr;
         int th, tn;
         enc_pick(Ho, cw.npad, &th, &tn);
-        int rc = wino ? raft_launch_conv_wino(a, epi, s) : enc_conv(a, kind, epi, th, tn, s);
+        int rc = wino4 ? raft_launch_conv_wino4(a, epi, s) : (wino ? raft_launch_conv_wino(a, epi, s) : enc_conv(a, kind, epi, th, tn, s));
         if (rc != RAFT_OK) return rc;
         if (a.stats) {
-            const int tiles = wino ? 2 * ((Ho + 3) / 4) * ((Wo + 31) / 32) : ((Ho + th - 1) / th) * ((Wo + 15) / 16);
+            const int tiles = wino4  ? 2 * ((Ho + 7) / 8) * ((Wo + 63) / 64)
+                              : wino ? 2 * ((Ho + 3) / 4) * ((Wo + 31) / 32)
+                                     : ((Ho + th - 1) / th) * ((Wo + 15) / 16);
             dim3 grid((cout + 63) / 64, n);
             in_finalize_kernel<<<grid, 1024, 0, s>>>(b.part, tiles, cw.npad, cout, gamma, beta, 1.0 / ((double)Ho * Wo),
                                                      ss_slot[slot][0], ss_slot[slot][1]);
@@ -314,11 +328,14 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
         }
         const EncKind k1 = stride == 2 ? ENC_3x3_S2 : ENC_3x3_S1;
         const int ni = 1 + blk * 3;   // index of this block's norm1 in in_gamma / in_beta
+        const bool w4 = ((wino4_mask >> (blk / 2)) & 1) &&
+                        (wino4_forced || (int64_t)n * ((Ho + 7) / 8) * ((Wo + 63) / 64) * ((F + 63) / 64) >= 100);
+        const raft_conv_weights *w44a = w4 ? &w->block_w44[blk][0] : nullptr, *w44b = w4 ? &w->block_w44[blk][1] : nullptr;
         if (inorm) {
             RAFT_TRY(conv(k1, c1, x, C, Hc, Wc, Ho, Wo, p1t, p1l, F, EPI_LINEAR, b.r1, nullptr, nullptr, nullptr, 0,
-                              w->in_gamma[ni], w->in_beta[ni], &w->block_w[blk][0]));
+                              w->in_gamma[ni], w->in_beta[ni], &w->block_w[blk][0], w44a));
             RAFT_TRY(conv(ENC_3x3_S1, c2, b.r1, F, Ho, Wo, Ho, Wo, 1, 1, F, EPI_LINEAR, b.r2, nullptr, ss_slot[0][0],
-                              ss_slot[0][1], 1, w->in_gamma[ni + 1], w->in_beta[ni + 1], &w->block_w[blk][1]));
+                              ss_slot[0][1], 1, w->in_gamma[ni + 1], w->in_beta[ni + 1], &w->block_w[blk][1], w44b));
             if (stride == 2) {
                 RAFT_REQUIRE(cd.wp != nullptr, RAFT_E_NULL);
                 RAFT_TRY(conv(ENC_1x1_S2, cd, x, C, Hc, Wc, Ho, Wo, 0, 0, F, EPI_LINEAR, b.rd, nullptr, nullptr, nullptr, 2,
@@ -329,7 +346,7 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
             }
         } else {
             RAFT_TRY(conv(k1, c1, x, C, Hc, Wc, Ho, Wo, p1t, p1l, F, EPI_RELU, b.r1, nullptr, nullptr, nullptr, -1, nullptr,
-                              nullptr, &w->block_w[blk][0]));
+                              nullptr, &w->block_w[blk][0], w44a));
             const float *shortcut = x;
             if (stride == 2) {
                 RAFT_REQUIRE(cd.wp != nullptr, RAFT_E_NULL);
@@ -338,7 +355,7 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
                 shortcut = b.rd;
             }
             RAFT_TRY(conv(ENC_3x3_S1, c2, b.r1, F, Ho, Wo, Ho, Wo, 1, 1, F, EPI_RES, y, shortcut, nullptr, nullptr, -1,
-                              nullptr, nullptr, &w->block_w[blk][1]));
+                              nullptr, nullptr, &w->block_w[blk][1], w44b));
         }
         float *t = x; x = y; y = t;
         C = F; Hc = Ho; Wc = Wo;

@@ -111,6 +111,8 @@ class _Encoder:
                 c.conv2 = cw
             elif field[0] == 'block_w':
                 c.block_w[field[1]][field[2]] = cw
+            elif field[0] == 'block_w44':
+                c.block_w44[field[1]][field[2]] = cw
             else:
                 c.block[field[1]][field[2]] = cw
         for idx, _, _ in norms:

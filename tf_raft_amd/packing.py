@@ -421,13 +421,13 @@ def _fold_bn(kernel, bias, w, name):
 
 def pack_encoder(weights: Dict[str, np.ndarray], prefix: str, norm_type):
     """Returns (convs, norms, dims): convs = [(field, wp, bias, npad)] with field in
-    {'conv1', 'conv2', ('block', i, j), ('block_w', i, j)} (block_w: Winograd-transformed copy of a
-    stride-1 3x3 convolution); norms = [(index, gamma, beta)] for instance norm;
+    {'conv1', 'conv2', ('block', i, j), ('block_w', i, j), ('block_w44', i, j)} (block_w / block_w44: Winograd F(2x2) /
+    F(4x4) transformed copies of a stride-1 3x3 convolution); norms = [(index, gamma, beta)] for instance norm;
     dims = (c0, c1, c2, c3, cout).  Batch norm is folded into the convolutions."""
     w = {k[len(prefix) + 1:]: np.asarray(v, dtype=np.float32) for k, v in weights.items() if k.startswith(prefix + '/')}
     convs, norms = [], []
 
-    def conv(field, name, norm_name, stem=False, wino_field=None):
+    def conv(field, name, norm_name, stem=False, wino_field=None, wino4_field=None):
         k, b = w[f'{name}/kernel'], w[f'{name}/bias']
         if norm_type == 'batch' and norm_name is not None:
             k, b = _fold_bn(k, b, w, norm_name)
@@ -436,6 +436,9 @@ def pack_encoder(weights: Dict[str, np.ndarray], prefix: str, norm_type):
         if wino_field is not None and k.shape[2] % 16 == 0:      # stride-1 3x3: also the Winograd F(2x2, 3x3) form
             wpw, bw, npw = pack_conv_winograd(k, b)
             convs.append((wino_field, wpw, bw, npw))
+        if wino4_field is not None and k.shape[2] % 16 == 0:     # and the F(4x4, 3x3) form (csrc/conv_wino4.h)
+            wp4, b4, np4 = pack_conv_winograd4(k, b)
+            convs.append((wino4_field, wp4, b4, np4))
 
     def inorm(index, name):
         if norm_type == 'instance':
@@ -449,8 +452,9 @@ def pack_encoder(weights: Dict[str, np.ndarray], prefix: str, norm_type):
             blk = (li - 1) * 2 + bi
             name = f'layer{li}/{bi}'
             strided = f'{name}/downsample/0/kernel' in w          # the block's first convolution has stride 2
-            conv(('block', blk, 0), f'{name}/conv1', f'{name}/norm1', wino_field=None if strided else ('block_w', blk, 0))
-            conv(('block', blk, 1), f'{name}/conv2', f'{name}/norm2', wino_field=('block_w', blk, 1))
+            conv(('block', blk, 0), f'{name}/conv1', f'{name}/norm1', wino_field=None if strided else ('block_w', blk, 0),
+                 wino4_field=None if strided else ('block_w44', blk, 0))
+            conv(('block', blk, 1), f'{name}/conv2', f'{name}/norm2', wino_field=('block_w', blk, 1), wino4_field=('block_w44', blk, 1))
             inorm(1 + blk * 3, f'{name}/norm1')
             inorm(2 + blk * 3, f'{name}/norm2')
             if f'{name}/downsample/0/kernel' in w:
