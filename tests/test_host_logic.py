@@ -368,7 +368,7 @@ def test_pyramid_layout_host_helper():
     assert lib.raft_corr_pyramid_layout(1, 4, 4, 4, off, lh, lw) == -2         # pooled away: RAFT_E_SHAPE
     assert lib.raft_corr_pyramid_layout(1, 8, 8, 5, off, lh, lw) == -3         # RAFT_E_UNSUPPORTED
     assert lib.raft_corr_build_workspace_floats(2, 56, 64, 256, 4) == 2 * 4800 * 256    # tile-padded rows
-    assert lib.raft_update_workspace_floats(4, 56, 64) == 4 * 3584 * 1408
+    assert lib.raft_update_workspace_floats(4, 56, 64) == 4 * 3584 * 1924      # + second [fh1 | mask.0] buffer, two flow copies
 
 
 def test_tiled_map_layout_round_trip():

@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256) flowhead2_kernel(const float *__restrict_
                                                         const float *__restrict__ bias, int B, int H, int W,
                                                         float *__restrict__ delta, float *__restrict__ coords1,
                                                         float *__restrict__ flow, float *__restrict__ flow2,
-                                                        int ldf2) {
+                                                        int ldf2, float *__restrict__ flow3 = nullptr) {
     constexpr int V = CIN / 64;   // channels per lane (4 or 2)
     static_assert(V == 4 || V == 2, "flowhead2: CIN must be 256 or 128");
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -515,6 +515,7 @@ __global__ void __launch_bounds__(256) flowhead2_kernel(const float *__restrict_
             const float f = c - (float)(comp ? py : px);     // coords0 = (x, y) grid
             flow[2 * m + comp] = f;
             if (flow2) flow2[m * ldf2 + comp] = f;
+            if (flow3) flow3[2 * m + comp] = f;       // the copy the (concurrent) mask branch of this iteration reads
         }
     }
 }
@@ -554,7 +555,10 @@ __global__ void __launch_bounds__(256) prepare_state_kernel(const float *__restr
 // workspace (floats per pixel): cor1 256 | corflo 256 [cor2 192 | flo2 64] | flo1 128 | z 128 | rh 128 | fm 512
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr int WS_COR1 = 0, WS_CORFLO = 256, WS_FLO1 = 512, WS_Z = 640, WS_RH = 768, WS_FM = 896, WS_PER_PIX = 1408;
+constexpr int WS_COR1 = 0, WS_CORFLO = 256, WS_FLO1 = 512, WS_Z = 640, WS_RH = 768, WS_FM = 896;
+// second [flow_head.conv1 | mask.0] buffer and two copies of the flow for the three-stream loop with the fused mask + upsampling
+// kernel: iteration i uses buffer i & 1, so the mask branch of iteration i - 1 is never overwritten by the main chain of i
+constexpr int WS_FM2 = 1408, WS_FLOWM = 1920, WS_PER_PIX = 1924;
 constexpr int HDIM = 128, XDIM = 256, CORR_LD = 352, CORR_USED = 324;
 constexpr int CDIM = 128;               // inp channels = x[:, 0:CDIM]; x[:, CDIM:XDIM] = [motion 126 | flow 2]
 constexpr int CTX_LD = 6 * HDIM;        // [z1 | r1 | q1 | z2 | r2 | q2] context terms per pixel
@@ -655,6 +659,18 @@ struct Overlap {
     hipStream_t s1, s2;
     hipEvent_t e_fh, e_f, e_fm, e_up;   // after fh2, after convf2, after fh1_mask0, after upsample
     bool have_up;                       // e_up has been recorded (false in the first iteration)
+    // Rotating buffers (all-predictions loop with the fused mask + upsampling kernel).  Every event operation on the MAIN
+    // stream costs the dependent chain 6 - 11 us of idle time (the next kernel is not dispatched under the previous one's
+    // tail: profiles/r07v_loop_gaps_b4.txt), and two of the four per iteration only protected buffers: the wait for the
+    // previous mask branch before fh1_mask0 / fh2 overwrite what it reads, and the record that let mask.2 start before fh2.
+    // With rot set, iteration i writes [fh1 | mask.0] and the mask branch's copy of the flow into buffer i & 1 and records
+    // e_rot[i & 1] after its mask + upsampling kernel; the FLOW branch of iteration i + 2 waits for that event on its own
+    // stream, and the main chain already waits for the flow branch before `conv` -- so the buffer is free before fh1_mask0
+    // of i + 2 rewrites it, with no event operation added to the main stream (two per iteration are left: the flow-branch
+    // join and the record after fh2).
+    bool rot;
+    int iter;
+    hipEvent_t e_rot[2];
 };
 #define RAFT_HIP(expr)                       \
     do {                                     \
@@ -683,7 +699,9 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     const int64_t M = (int64_t)B * h * w;
     float *ws = st->ws;
     float *cor1 = ws + M * WS_COR1, *corflo = ws + M * WS_CORFLO, *flo1 = ws + M * WS_FLO1;
-    float *zb = ws + M * WS_Z, *rh = ws + M * WS_RH, *fm = ws + M * WS_FM;
+    const bool rot = ov && ov->rot && with_mask && flow_up_fused != nullptr;
+    float *zb = ws + M * WS_Z, *rh = ws + M * WS_RH, *fm = ws + M * ((rot && (ov->iter & 1)) ? WS_FM2 : WS_FM);
+    float *flowm = rot ? ws + M * WS_FLOWM + (ov->iter & 1) * 2 * M : nullptr;
 
     // ---- BasicMotionEncoder (update.py:97-106)
     if (fused_src) {   // cor = relu(convc1(retrieve(coords1)))   lookup + 1x1, 324 -> 256, one kernel
@@ -701,6 +719,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         RAFT_MARK();
     }
     if (ov) RAFT_HIP(hipStreamWaitEvent(sf, ov->e_fh, 0));   // flow of the previous iteration is final
+    if (rot && ov->iter >= 2) RAFT_HIP(hipStreamWaitEvent(sf, ov->e_rot[ov->iter & 1], 0));   // mask branch of iteration - 2: its buffers are free
     {   // flo = relu(convf1(flow))            7x7, 2 -> 128
         conv7x7_c2_kernel<128><<<B * ((h + 3) / 4) * ((w + 15) / 16), 256, 0, sf>>>(st->flow, wts->convf1.wp, wts->convf1.bias, B, h, w, flo1, 128);
         RAFT_TRY(raft_launch_status());
@@ -746,7 +765,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
             RAFT_MARK();
         }
     }
-    if (ov && ov->have_up) RAFT_HIP(hipStreamWaitEvent(s, ov->e_up, 0));   // mask2 / upsample of the previous iteration
+    if (ov && ov->have_up && !rot) RAFT_HIP(hipStreamWaitEvent(s, ov->e_up, 0));   // mask2 / upsample of the previous iteration
     if (with_mask) {   // relu(flow_head.conv1(net)) | relu(mask.0(net))   3x3, 128 -> 256 + 256
         ConvArgs a = conv_args(wts->fh1_mask0, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 512, fm, 512);
         RAFT_TRY(launch_conv3x3(wts->fh1_mask0, wts->fh1_mask0_w, 8, a, EPI_RELU, s, false, &wts->fh1_mask0_w44));
@@ -756,13 +775,13 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         ConvArgs a = conv_args(w44 ? wts->fh1_w44 : wts->fh1_w, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 256, fm, 512);
         RAFT_TRY(w44 ? raft_launch_conv_wino4(a, EPI_RELU, s, wts->fh1_mask0_w44.npad) : raft_launch_conv_wino(a, EPI_RELU, s));
     }
-    if (ov) {
+    if (ov && with_mask && flow_up_fused == nullptr) {   // two-kernel mask branch: mask.2 may start before fh2
         RAFT_HIP(hipEventRecord(ov->e_fm, s));
         RAFT_HIP(hipStreamWaitEvent(sm, ov->e_fm, 0));
     }
     {   // delta = flow_head.conv2(.), coords1 += delta, flow = coords1 - coords0
         flowhead2_kernel<256><<<raft_ceil_div((int64_t)B * ((h + 1) / 2) * ((w + 3) / 4), 4), 256, 0, s>>>(fm, 512, wts->fh2.wp, wts->fh2.bias, B, h, w,
-                                                                   st->delta, st->coords1, st->flow, st->x + 254, XDIM);
+                                                                   st->delta, st->coords1, st->flow, st->x + 254, XDIM, flowm);
         RAFT_TRY(raft_launch_status());
         RAFT_MARK();
     }
@@ -771,7 +790,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         // mask.2 and the convex upsampling as ONE kernel (mask_upsample.hip): the mask is never written.  Besides fm (the mask
         // branch already waits for fh1_mask0) it needs the flow fh2 has just written.
         if (ov) RAFT_HIP(hipStreamWaitEvent(sm, ov->e_fh, 0));
-        RAFT_TRY(raft_launch_mask_upsample(fm + 256, 512, wts->mask2.wp, wts->mask2.bias, wts->mask2.npad, st->flow, B, h, w,
+        RAFT_TRY(raft_launch_mask_upsample(fm + 256, 512, wts->mask2.wp, wts->mask2.bias, wts->mask2.npad, rot ? flowm : st->flow, B, h, w,
                                            0.25f, flow_up_fused, sm));
         RAFT_MARK();
     } else if (with_mask) {   // mask = 0.25 * mask.2(.)             1x1, 256 -> 576
@@ -919,6 +938,9 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
     ov.e_f = ctx->ev[1];
     ov.e_fm = ctx->ev[2];
     ov.e_up = ctx->ev[3];
+    ov.e_rot[0] = ctx->ev[2];   // e_fm is not used in that mode
+    ov.e_rot[1] = ctx->ev[3];
+    ov.rot = !final_only && mask_is_fused(wts) && raft_opt(RAFT_OPT_LOOP_ROTATE, 1) != 0;
     const int64_t up = (int64_t)B * 64 * h * w * 2;
     int rc = (int)hipEventRecord(ov.e_fh, s);   // state prepared on `stream`: the flow branch may start
     for (int i = 0; i < iters && rc == RAFT_OK; ++i) {
@@ -927,6 +949,7 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
         rc = fused ? RAFT_OK : loop_lookup(src, st, B, h, w, stream);
         float *up_i = flow_up + (final_only ? 0 : i * up);
         const bool mf = with_mask && mask_is_fused(wts);
+        ov.iter = i;
         if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov, with_mask, fused ? &src : nullptr, mf ? up_i : nullptr);
         if (!with_mask) continue;
         if (!mf) {
@@ -934,6 +957,7 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
             if (rc == RAFT_OK) rc = (int)hipStreamWaitEvent(ov.s2, ov.e_fh, 0);
             if (rc == RAFT_OK) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, up_i, ov.s2);
         }
+        if (ov.rot) ov.e_up = ov.e_rot[i & 1];
         if (rc == RAFT_OK) rc = (int)hipEventRecord(ov.e_up, ov.s2);
         ov.have_up = true;
     }

@@ -50,6 +50,19 @@ for name, ks in (('whole call', call), ('prediction loop', call[first_loop:])):
     print(f'{label} {name}: {s["n"]} kernels, wall {s["wall"]:.3f} ms, union busy {s["busy"]:.3f}, idle {s["idle"]:.3f} '
           f'({s["gaps"]} gaps, median {s["gap_med"]:.2f} us, p90 {s["gap_p90"]:.2f} us), >= 2 kernels in flight {s["over"]:.3f} ms, '
           f'sum of kernel durations {s["sum"]:.3f} ms')
+# which kernel boundaries the idle gaps sit at: (kernel that ended last -> kernel that starts after the gap)
+short = lambda n: n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:34]   # noqa: E731
+ctx, end, last = Counter(), call[first_loop][1], call[first_loop]
+dur = {}
+for r in call[first_loop + 1:]:
+    if r[0] > end:
+        key = (short(last[2]) + ' q' + last[3], short(r[2]) + ' q' + r[3])
+        ctx[key] += 1
+        dur[key] = dur.get(key, 0) + (r[0] - end)
+    if r[1] > end:
+        end, last = r[1], r
+for key, c in ctx.most_common(8):
+    print(f'  idle x{c:3d} mean {dur[key] / c / 1e3:5.2f} us  after {key[0]}  before {key[1]}')
 q = Counter((r[3], r[2].split('(')[0].replace('void ', '')[:40]) for r in call[first_loop:])
 by_queue = {}
 for (queue, kn), c in q.items():
