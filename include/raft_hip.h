@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 212          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 213          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -472,6 +472,12 @@ int raft_relu_backward_f32(const float *y, const float *dy, float *dx, int64_t n
 int64_t raft_conv2d_wgrad_workspace_floats(int cin, int cout, int B, int H, int W, int kh, int kw);
 int raft_conv2d_wgrad_f32(const float *x, int ldx, int cin, const float *dy, int ldy, int cout, int B, int H, int W,
                           int kh, int kw, float *d_kernel, float *d_bias, float *workspace, void *stream);
+/* The same gradient summed over nseg (1..32) pairs (xs[i], dys[i]) of identical geometry in ONE pixel reduction; xs / dys are
+ * HOST arrays of device pointers (copied into the kernel arguments).  The iterations of a training step share the update
+ * block's weights (reference model.py:91-109): one launch over all of them replaces nseg launches, nseg second-stage sums and
+ * nseg - 1 accumulations per layer.  Workspace: raft_conv2d_wgrad_workspace_floats(cin, cout, B * nseg, H, W, kh, kw). */
+int raft_conv2d_wgrad_multi_f32(const float *const *xs, const float *const *dys, int nseg, int ldx, int cin, int ldy, int cout,
+                                int B, int H, int W, int kh, int kw, float *d_kernel, float *d_bias, float *workspace, void *stream);
 
 /* ---- second slice: everything one BasicUpdateBlock call needs (tf_raft_amd/grad.py basic_update_block_backward) */
 

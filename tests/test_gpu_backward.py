@@ -295,6 +295,53 @@ def test_loop_backward_through_time_matches_autograd(rng):
         worst_w = max(worst_w, rel2)
         assert rel2 <= 5e-3, (name, rel2)
     report('loop backward through time, 3 iterations', worst_rel_err_inputs=worst, worst_rel_l2_weights=worst_w)
+    # the weight gradients evaluated per iteration and accumulated (what a bf16 tape does) are the same numbers up to the
+    # order of the fp32 pixel sums
+    _, _, _, wg_it = grad.loop_backward(wts, dev, tape, d_preds, defer_wgrad=False)
+    assert sorted(wg_it) == sorted(wg)
+    worst_d = 0.0
+    for name in sorted(wg):
+        a, b_ = _np(wg[name]).astype(np.float64), _np(wg_it[name]).astype(np.float64)
+        worst_d = max(worst_d, float(np.linalg.norm(a - b_) / max(np.linalg.norm(b_), 1e-30)))
+    report('deferred vs per-iteration weight gradients', worst_rel_l2=worst_d)
+    assert worst_d <= 2e-5
+
+
+def test_conv2d_wgrad_multi_is_the_sum_of_the_single_gradients(rng):
+    """raft_conv2d_wgrad_multi_f32: the kernel / bias gradient over several (x, dy) pairs in one pixel reduction, against the
+    float64 sum of the per-pair gradients, for every kernel shape of the library and ragged tiles."""
+    import ctypes as C
+    from tf_raft_amd import _dev
+    from tf_raft_amd._ffi import check
+    lib = _dev.lib()
+    dev = _dev.require_gpu()
+    for kh, kw, cin, cout, B, H, W, nseg in ((3, 3, 64, 96, 2, 13, 21, 3), (1, 1, 128, 68, 1, 9, 33, 5), (1, 5, 96, 64, 2, 8, 16, 2),
+                                             (5, 1, 64, 128, 1, 16, 16, 12), (3, 3, 128, 256, 1, 12, 31, 1)):
+        xs = [torch.as_tensor(rng.normal(size=(B, H, W, cin)).astype(np.float32)).to(dev) for _ in range(nseg)]
+        dys = [torch.as_tensor(rng.normal(size=(B, H, W, cout)).astype(np.float32)).to(dev) for _ in range(nseg)]
+        want_k = np.zeros((kh, kw, cin, cout))
+        want_b = np.zeros((cout,))
+        for x, dy in zip(xs, dys):
+            xd = torch.nn.functional.pad(x.double().cpu(), (0, 0, (kw - 1) // 2, (kw - 1) // 2, (kh - 1) // 2, (kh - 1) // 2))
+            dd = dy.double().cpu()
+            for ky in range(kh):
+                for kx in range(kw):
+                    want_k[ky, kx] += torch.einsum('bhwi,bhwo->io', xd[:, ky:ky + H, kx:kx + W], dd).numpy()
+            want_b += dd.sum(dim=(0, 1, 2)).numpy()
+        ws = torch.empty((int(lib.raft_conv2d_wgrad_workspace_floats(cin, cout, B * nseg, H, W, kh, kw)),), device=dev)
+        dk = torch.empty((kh, kw, cin, cout), device=dev)
+        db = torch.empty((cout,), device=dev)
+        px = (C.c_void_p * nseg)(*[_dev.ptr(t) for t in xs])
+        pd = (C.c_void_p * nseg)(*[_dev.ptr(t) for t in dys])
+        check(lib.raft_conv2d_wgrad_multi_f32(px, pd, nseg, cin, cin, cout, cout, B, H, W, kh, kw, _dev.ptr(dk), _dev.ptr(db),
+                                              _dev.ptr(ws), _dev.stream_ptr()), 'wgrad_multi')
+        ek = float(np.abs(_np(dk) - want_k).max() / np.abs(want_k).max())
+        eb = float(np.abs(_np(db) - want_b).max() / np.abs(want_b).max())
+        report(f'wgrad multi {kh}x{kw} {cin}->{cout} x{nseg}', rel_kernel=ek, rel_bias=eb)
+        assert ek <= 2e-5 and eb <= 2e-5
+    # argument checks: more segments than the kernel arguments hold
+    assert lib.raft_conv2d_wgrad_multi_f32(px, pd, 33, cin, cin, cout, cout, B, H, W, kh, kw, _dev.ptr(dk), _dev.ptr(db),
+                                           _dev.ptr(ws), _dev.stream_ptr()) < 0
 
 
 def _reference_train_steps(wts, batches, iters, lr_fn, wd, clip_norm, n_steps):

@@ -239,18 +239,21 @@ extern "C" int raft_relu_backward_f32(const float *y, const float *dy, float *dx
 // writes the Keras-layout kernel gradient.  The bias gradient (column sums of dy) takes the same two steps.
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr int WG_TH = 4, WG_TW = 16, WG_PS = 80, WG_MAXT = 9;
+constexpr int WG_TH = 4, WG_TW = 16, WG_PS = 80, WG_MAXT = 9, WG_MAXSEG = 32;
 
+// x / dy may be SEGMENTED: nseg tensors of (B, H, W, .) each (the iterations of the prediction loop share their weights, so
+// one launch sums the pixel reduction over all of them: raft_conv2d_wgrad_multi_f32); tile t lives in segment t / tiles_seg
 struct WgradArgs {
-    const float *x, *dy;
+    const float *x[WG_MAXSEG], *dy[WG_MAXSEG];
     float *part;          // [S][T][cin][cout]
-    int ldx, ldy, cin, cout, B, H, W, kh, kw, S, tiles_y, tiles_x;
+    int ldx, ldy, cin, cout, B, H, W, kh, kw, S, tiles_y, tiles_x, nseg, tiles_seg;
 };
 
 template <int KH, int KW>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
     constexpr int T = KH * KW, HH = WG_TH + KH - 1, HW = WG_TW + KW - 1;
     constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;
+    constexpr int NX = (HH * HW * 16 + 255) / 256, NY = WG_TH * WG_TW * 16 / 256;   // 16-byte items per thread and tile
     static_assert(T <= WG_MAXT, "accumulator budget");
     __shared__ __attribute__((aligned(16))) float sX[HH * HW * WG_PS];
     __shared__ __attribute__((aligned(16))) float sY[WG_TH * WG_TW * WG_PS];
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
     const int r = lane & 15, g = lane >> 4;
     const int cib = blockIdx.x, cob = blockIdx.y, sl = blockIdx.z;
     const int ci0 = cib * 64, co0 = cob * 64;
-    const int ntiles = p.B * p.tiles_y * p.tiles_x;
+    const int ntiles = p.nseg * p.tiles_seg;
     const int t_lo = (int)((long)ntiles * sl / p.S), t_hi = (int)((long)ntiles * (sl + 1) / p.S);
 
     f32x4 acc[T][4];
@@ -267,30 +270,45 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = t_lo; tile < t_hi; ++tile) {
-        const int txi = tile % p.tiles_x, tyi = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    // the NEXT tile's halo / dy items are fetched into registers while the current tile is multiplied out of LDS
+    f32x4 rx[NX], ry[NY];
+    const int c4 = tid & 15;
+    auto fetch = [&](int tile) {
+        const int seg = tile / p.tiles_seg, tl = tile - seg * p.tiles_seg;
+        const int txi = tl % p.tiles_x, tyi = (tl / p.tiles_x) % p.tiles_y, b = tl / (p.tiles_x * p.tiles_y);
         const int y0 = tyi * WG_TH, x0 = txi * WG_TW;
-        __syncthreads();                                   // previous tile's fragments have been read
-        // stage x halo: items = (halo pixel, 16-byte channel quad of the 64-channel block)
-        for (int it = tid; it < HH * HW * 16; it += 256) {
-            const int hp = it >> 4, c4 = it & 15;
+        const float *xs = p.x[seg], *ds = p.dy[seg];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int hp = (tid + 256 * i) >> 4;
             const int yy = y0 - PT + hp / HW, xx = x0 - PL + hp % HW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int c = ci0 + c4 * 4;
-            if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && c < p.cin)
-                v = *(const f32x4 *)(p.x + ((int64_t)(b * p.H + yy) * p.W + xx) * p.ldx + c);
-            *(f32x4 *)(sX + hp * WG_PS + c4 * 4) = v;
+            rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (hp < HH * HW && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && c < p.cin)
+                rx[i] = *(const f32x4 *)(xs + ((int64_t)(b * p.H + yy) * p.W + xx) * p.ldx + c);
         }
-        for (int it = tid; it < WG_TH * WG_TW * 16; it += 256) {
-            const int pp = it >> 4, c4 = it & 15;
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int pp = (tid + 256 * i) >> 4;
             const int yy = y0 + pp / WG_TW, xx = x0 + pp % WG_TW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int c = co0 + c4 * 4;
+            ry[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (yy < p.H && xx < p.W && c < p.cout)
-                v = *(const f32x4 *)(p.dy + ((int64_t)(b * p.H + yy) * p.W + xx) * p.ldy + c);
-            *(f32x4 *)(sY + pp * WG_PS + c4 * 4) = v;
+                ry[i] = *(const f32x4 *)(ds + ((int64_t)(b * p.H + yy) * p.W + xx) * p.ldy + c);
         }
+    };
+    if (t_lo < t_hi) fetch(t_lo);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        __syncthreads();                                   // previous tile's fragments have been read
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int hp = (tid + 256 * i) >> 4;
+            if (hp < HH * HW) *(f32x4 *)(sX + hp * WG_PS + c4 * 4) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NY; ++i) *(f32x4 *)(sY + ((tid + 256 * i) >> 4) * WG_PS + c4 * 4) = ry[i];
         __syncthreads();
+        if (tile + 1 < t_hi) fetch(tile + 1);
         // k-steps: 4 consecutive pixels of a tile row; lane (r, g): pixel 4 * step + g
 #pragma unroll 2
         for (int step = 0; step < WG_TH * WG_TW / 4; ++step) {
@@ -330,19 +348,31 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
 
 // column sums of dy: partial[blk][co] over a pixel range, then the same ordered reduction.  Thread = (pixel lane tid / 64,
 // channel tid % 64): 64-channel chunks, four pixels in flight per chunk, the four lanes joined through LDS in fixed order.
-__global__ void __launch_bounds__(256) bias_grad_partial_kernel(const float *__restrict__ dy, int ldy, int cout, int64_t M, int nblk,
-                                                                float *__restrict__ part) {
+// Segmented like the kernel gradient: pixel m of the concatenation lives in segment m / Mseg.
+struct BiasGradArgs {
+    const float *dy[WG_MAXSEG];
+    int64_t Mseg;
+    int nseg, ldy, cout, nblk;
+    float *part;
+};
+__global__ void __launch_bounds__(256) bias_grad_partial_kernel(BiasGradArgs p) {
     __shared__ float sh[4][64];
     const int blk = blockIdx.x, cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
-    const int64_t lo = M * blk / nblk, hi = M * (blk + 1) / nblk;
-    for (int c0 = 0; c0 < cout; c0 += 64) {
+    const int64_t M = p.Mseg * p.nseg;
+    const int64_t lo = M * blk / p.nblk, hi = M * (blk + 1) / p.nblk;
+    for (int c0 = 0; c0 < p.cout; c0 += 64) {
         const int c = c0 + cl;
         float s = 0.f;
-        if (c < cout)
-            for (int64_t m = lo + pr; m < hi; m += 4) s += dy[m * ldy + c];
+        if (c < p.cout)
+            for (int seg = (int)(lo / p.Mseg); seg < p.nseg && (int64_t)seg * p.Mseg < hi; ++seg) {   // the block's pieces, in order
+                const int64_t base = (int64_t)seg * p.Mseg;
+                const int64_t a = (lo > base ? lo : base) - base, b = (hi < base + p.Mseg ? hi : base + p.Mseg) - base;
+                const float *d = p.dy[seg];
+                for (int64_t m = a + pr; m < b; m += 4) s += d[m * p.ldy + c];
+            }
         sh[pr][cl] = s;
         __syncthreads();
-        if (pr == 0 && c < cout) part[(int64_t)blk * cout + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        if (pr == 0 && c < p.cout) p.part[(int64_t)blk * p.cout + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
         __syncthreads();
     }
 }
@@ -363,22 +393,34 @@ extern "C" int64_t raft_conv2d_wgrad_workspace_floats(int cin, int cout, int B, 
     return (int64_t)wgrad_slices(cin, cout, B, H, W) * kh * kw * cin * cout + (int64_t)BIAS_BLOCKS * cout;
 }
 
-extern "C" int raft_conv2d_wgrad_f32(const float *x, int ldx, int cin, const float *dy, int ldy, int cout, int B, int H, int W,
-                                     int kh, int kw, float *d_kernel, float *d_bias, float *workspace, void *stream) {
-    RAFT_REQUIRE_PTR(x);
-    RAFT_REQUIRE_PTR(dy);
+// nseg (x, dy) pairs of identical geometry: d_kernel / d_bias = the sums over all of them, in ONE pixel reduction
+static int wgrad_launch(const float *const *xs, const float *const *dys, int nseg, int ldx, int cin, int ldy, int cout, int B,
+                        int H, int W, int kh, int kw, float *d_kernel, float *d_bias, float *workspace, void *stream) {
+    RAFT_REQUIRE_PTR(xs);
+    RAFT_REQUIRE_PTR(dys);
     RAFT_REQUIRE_PTR(d_kernel);
     RAFT_REQUIRE_PTR(workspace);
+    RAFT_REQUIRE(nseg >= 1 && nseg <= WG_MAXSEG, RAFT_E_SHAPE);
     RAFT_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, RAFT_E_SHAPE);
     RAFT_REQUIRE(cin % 4 == 0 && cout % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, RAFT_E_UNSUPPORTED);
-    RAFT_REQUIRE(raft_aligned16(x) && raft_aligned16(dy), RAFT_E_ALIGN);
     hipStream_t s = (hipStream_t)stream;
-    WgradArgs a;
-    a.x = x; a.dy = dy; a.part = workspace;
+    WgradArgs a = {};
+    BiasGradArgs ba = {};
+    for (int i = 0; i < nseg; ++i) {
+        RAFT_REQUIRE_PTR(xs[i]);
+        RAFT_REQUIRE_PTR(dys[i]);
+        RAFT_REQUIRE(raft_aligned16(xs[i]) && raft_aligned16(dys[i]), RAFT_E_ALIGN);
+        a.x[i] = xs[i];
+        a.dy[i] = dys[i];
+        ba.dy[i] = dys[i];
+    }
+    a.part = workspace;
     a.ldx = ldx; a.ldy = ldy; a.cin = cin; a.cout = cout; a.B = B; a.H = H; a.W = W; a.kh = kh; a.kw = kw;
-    a.S = wgrad_slices(cin, cout, B, H, W);
+    a.S = wgrad_slices(cin, cout, B * nseg, H, W);
     a.tiles_y = (H + WG_TH - 1) / WG_TH;
     a.tiles_x = (W + WG_TW - 1) / WG_TW;
+    a.nseg = nseg;
+    a.tiles_seg = B * a.tiles_y * a.tiles_x;
     const dim3 grid((cin + 63) / 64, (cout + 63) / 64, a.S);
     if (kh == 1 && kw == 1)
         conv_wgrad_kernel<1, 1><<<grid, 256, 0, s>>>(a);
@@ -396,13 +438,29 @@ extern "C" int raft_conv2d_wgrad_f32(const float *x, int ldx, int cin, const flo
     RAFT_TRY(raft_launch_status());
     if (d_bias) {
         float *bp = workspace + (int64_t)a.S * n;
-        const int64_t M = (int64_t)B * H * W;
-        bias_grad_partial_kernel<<<BIAS_BLOCKS, 256, 0, s>>>(dy, ldy, cout, M, BIAS_BLOCKS, bp);
+        ba.Mseg = (int64_t)B * H * W;
+        ba.nseg = nseg; ba.ldy = ldy; ba.cout = cout; ba.nblk = BIAS_BLOCKS; ba.part = bp;
+        bias_grad_partial_kernel<<<BIAS_BLOCKS, 256, 0, s>>>(ba);
         RAFT_TRY(raft_launch_status());
         wgrad_reduce_kernel<<<raft_ceil_div(cout, 256), 256, 0, s>>>(bp, BIAS_BLOCKS, cout, d_bias);
         RAFT_TRY(raft_launch_status());
     }
     return RAFT_OK;
+}
+
+extern "C" int raft_conv2d_wgrad_f32(const float *x, int ldx, int cin, const float *dy, int ldy, int cout, int B, int H, int W,
+                                     int kh, int kw, float *d_kernel, float *d_bias, float *workspace, void *stream) {
+    return wgrad_launch(&x, &dy, 1, ldx, cin, ldy, cout, B, H, W, kh, kw, d_kernel, d_bias, workspace, stream);
+}
+
+// The same gradient summed over nseg (<= 32) pairs (xs[i], dys[i]) of identical geometry -- host arrays of device pointers --
+// in one pixel reduction: the 12 iterations of a training step share the update block's weights, and one launch over all of
+// them replaces 12 launches + 12 second-stage sums + 11 accumulations per layer.  Workspace:
+// raft_conv2d_wgrad_workspace_floats(cin, cout, B * nseg, H, W, kh, kw).
+extern "C" int raft_conv2d_wgrad_multi_f32(const float *const *xs, const float *const *dys, int nseg, int ldx, int cin, int ldy,
+                                           int cout, int B, int H, int W, int kh, int kw, float *d_kernel, float *d_bias,
+                                           float *workspace, void *stream) {
+    return wgrad_launch(xs, dys, nseg, ldx, cin, ldy, cout, B, H, W, kh, kw, d_kernel, d_bias, workspace, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -594,7 +652,12 @@ extern "C" int raft_conv7x7_c2_backward_f32(const float *flow, const float *dy, 
     RAFT_TRY(raft_launch_status());
     wgrad_reduce_kernel<<<raft_ceil_div(98 * cout, 256), 256, 0, s>>>(workspace, C7_SLICES, (int64_t)98 * cout, d_kernel);
     float *bp = workspace + (int64_t)C7_SLICES * 98 * cout;
-    bias_grad_partial_kernel<<<C7_SLICES, 256, 0, s>>>(dy, ldy, cout, M, C7_SLICES, bp);
+    {
+        BiasGradArgs ba = {};
+        ba.dy[0] = dy;
+        ba.Mseg = M; ba.nseg = 1; ba.ldy = ldy; ba.cout = cout; ba.nblk = C7_SLICES; ba.part = bp;
+        bias_grad_partial_kernel<<<C7_SLICES, 256, 0, s>>>(ba);
+    }
     wgrad_reduce_kernel<<<raft_ceil_div(cout, 256), 256, 0, s>>>(bp, C7_SLICES, cout, d_bias);
     return raft_launch_status();
 }

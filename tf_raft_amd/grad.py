@@ -139,11 +139,62 @@ def corr_lookup_backward(corr_block, coords, d_out, d_pyramid=None, want_pyramid
     return _dev.wrap(d_coords), d_pyramid
 
 
-def conv2d_backward(x, kernel, dy, y=None):
+class WgradDefer:
+    """Weight gradients of layers that are applied several times with the SAME weights (the update block over the iterations
+    of the prediction loop, reference model.py:91-109), evaluated ONCE at the end: ``add`` keeps the (input, masked upstream
+    gradient) pair of an application, ``finish`` runs one ``raft_conv2d_wgrad_multi_f32`` per layer over all of them -- a single
+    pixel reduction instead of one launch + one second-stage sum + one accumulation per application (12 per layer and step at
+    the reference's training shape).  Costs the memory of the kept upstream gradients (the inputs are on the tape anyway)."""
+    MAX_SEG = 32
+
+    def __init__(self):
+        self.jobs = {}
+
+    def add(self, key, x, dy, kshape, trim=None):
+        job = self.jobs.setdefault(key, dict(kshape=tuple(kshape), xs=[], dys=[], trim=trim))
+        if job['kshape'] != tuple(kshape) or (job['xs'] and job['xs'][0].shape != x.shape):
+            raise ValueError(f'{key}: applications of one layer must share their geometry')
+        job['xs'].append(x)
+        job['dys'].append(dy)
+
+    def finish(self):
+        """{key: (d_kernel, d_bias)} -- sums over every application added under the key."""
+        lib = _dev.lib()
+        out = {}
+        for key, job in self.jobs.items():
+            kh, kw, cin, cout = job['kshape']
+            B, H, W, _ = job['xs'][0].shape
+            dev = job['xs'][0].device
+            dk = torch.zeros((kh, kw, cin, cout), device=dev, dtype=torch.float32)
+            db = torch.zeros((cout,), device=dev, dtype=torch.float32)
+            for lo in range(0, len(job['xs']), self.MAX_SEG):
+                xs, dys = job['xs'][lo:lo + self.MAX_SEG], job['dys'][lo:lo + self.MAX_SEG]
+                n = len(xs)
+                ws = torch.empty((int(lib.raft_conv2d_wgrad_workspace_floats(cin, cout, B * n, H, W, kh, kw)),), device=dev,
+                                 dtype=torch.float32)
+                px = (C.c_void_p * n)(*[_dev.ptr(t) for t in xs])
+                pd = (C.c_void_p * n)(*[_dev.ptr(t) for t in dys])
+                first = lo == 0
+                dk_i = dk if first else torch.empty_like(dk)
+                db_i = db if first else torch.empty_like(db)
+                check(lib.raft_conv2d_wgrad_multi_f32(px, pd, n, cin, cin, cout, cout, B, H, W, kh, kw, _dev.ptr(dk_i), _dev.ptr(db_i),
+                                                      _dev.ptr(ws), _dev.stream_ptr()), 'conv2d_wgrad_multi')
+                if not first:
+                    dk, db = _axpby(1.0, dk, 1.0, dk_i), _axpby(1.0, db, 1.0, db_i)
+            if job['trim'] is not None:
+                ci, co = job['trim']
+                dk, db = dk[:, :, :ci, :co].contiguous(), db[:co].contiguous()
+            out[key] = (dk, db)
+        self.jobs = {}
+        return out
+
+
+def conv2d_backward(x, kernel, dy, y=None, defer=None):
     """Backward of ``y = [relu](conv2d(x, kernel) + bias)`` (Keras Conv2D, stride 1, 'same'; reference update.py:10-11,
     91-95, 138-140).  ``x`` (B, H, W, Cin), ``kernel`` (kh, kw, Cin, Cout) NumPy in Keras layout, ``dy`` (B, H, W, Cout);
     pass the forward output ``y`` to apply the relu mask first.  Returns ``(dx, d_kernel, d_bias)`` device tensors.
-    Cin and Cout must be multiples of 4 (every layer of the update block except the flow-carrying ones)."""
+    Cin and Cout must be multiples of 4 (every layer of the update block except the flow-carrying ones).
+    ``defer = (WgradDefer, key[, trim])``: the kernel / bias gradient is left to ``WgradDefer.finish`` (None returned here)."""
     x = _f32(x)
     dy = _f32(dy)
     kernel = (kernel if type(kernel) is torch.Tensor else kernel.as_subclass(torch.Tensor)) if _is_t(kernel) else np.asarray(kernel, dtype=np.float32)
@@ -159,12 +210,18 @@ def conv2d_backward(x, kernel, dy, y=None):
               'relu_backward')
         dy = masked
     # kernel / bias gradient
-    ws = torch.empty((int(lib.raft_conv2d_wgrad_workspace_floats(cin, cout, B, H, W, kh, kw)),), device=x.device,
-                     dtype=torch.float32)
-    d_kernel = torch.empty((kh, kw, cin, cout), device=x.device, dtype=torch.float32)
-    d_bias = torch.empty((cout,), device=x.device, dtype=torch.float32)
-    check(lib.raft_conv2d_wgrad_f32(_dev.ptr(x), cin, cin, _dev.ptr(dy), cout, cout, B, H, W, kh, kw, _dev.ptr(d_kernel),
-                                    _dev.ptr(d_bias), _dev.ptr(ws), _dev.stream_ptr()), 'conv2d_wgrad')
+    if defer is not None:
+        x = x.contiguous()
+        dy = dy.contiguous()
+        defer[0].add(defer[1], x, dy, (kh, kw, cin, cout), defer[2] if len(defer) > 2 else None)
+        d_kernel = d_bias = None
+    else:
+        ws = torch.empty((int(lib.raft_conv2d_wgrad_workspace_floats(cin, cout, B, H, W, kh, kw)),), device=x.device,
+                         dtype=torch.float32)
+        d_kernel = torch.empty((kh, kw, cin, cout), device=x.device, dtype=torch.float32)
+        d_bias = torch.empty((cout,), device=x.device, dtype=torch.float32)
+        check(lib.raft_conv2d_wgrad_f32(_dev.ptr(x), cin, cin, _dev.ptr(dy), cout, cout, B, H, W, kh, kw, _dev.ptr(d_kernel),
+                                        _dev.ptr(d_bias), _dev.ptr(ws), _dev.stream_ptr()), 'conv2d_wgrad')
     # input gradient: the forward convolution of dy with the flipped, transposed kernel
     cpad = packing.round_up(cout, 32)
 
@@ -176,6 +233,8 @@ def conv2d_backward(x, kernel, dy, y=None):
     dx = torch.empty((B, H, W, cin), device=x.device, dtype=torch.float32)
     check(lib.raft_conv2d_f32(_dev.ptr(dyp), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw, npad,
                               cin, 0, 1.0, _dev.ptr(dx), cin, _dev.stream_ptr()), 'conv2d dgrad')
+    if defer is not None:
+        return _dev.wrap(dx), None, None
     return _dev.wrap(dx), _dev.wrap(d_kernel), _dev.wrap(d_bias)
 
 
@@ -208,8 +267,9 @@ def _axpby(alpha, a, beta=0.0, b=None):
     return out
 
 
-def _conv_bwd(x, kernel, dy, y=None):
-    """``conv2d_backward`` for any channel counts: pads Cin / Cout to multiples of 4 around the kernels and trims."""
+def _conv_bwd(x, kernel, dy, y=None, defer=None):
+    """``conv2d_backward`` for any channel counts: pads Cin / Cout to multiples of 4 around the kernels and trims.
+    ``defer = (WgradDefer, key)``: see ``conv2d_backward``."""
     kernel = (kernel if type(kernel) is torch.Tensor else kernel.as_subclass(torch.Tensor)) if _is_t(kernel) else np.asarray(kernel, dtype=np.float32)
     kh, kw, cin, cout = kernel.shape
     ci4, co4 = packing.round_up(cin, 4), packing.round_up(cout, 4)
@@ -229,10 +289,14 @@ def _conv_bwd(x, kernel, dy, y=None):
         if y is not None:
             yp = torch.zeros((B, H, W, co4), device=x.device, dtype=torch.float32)
             yp[..., :cout] = y
-        dx, dk, db = conv2d_backward(xp, kp, dyp, y=yp)
+        dx, dk, db = conv2d_backward(xp, kp, dyp, y=yp, defer=None if defer is None else (defer[0], defer[1], (cin, cout)))
         t = lambda v: v.as_subclass(torch.Tensor)
+        if defer is not None:
+            return t(dx)[..., :cin].contiguous(), None, None
         return t(dx)[..., :cin].contiguous(), t(dk)[:, :, :cin, :cout].contiguous(), t(db)[:cout].contiguous()
-    dx, dk, db = conv2d_backward(x, kernel, dy, y=y)
+    dx, dk, db = conv2d_backward(x, kernel, dy, y=y, defer=defer)
+    if defer is not None:
+        return dx.as_subclass(torch.Tensor), None, None
     return dx.as_subclass(torch.Tensor), dk.as_subclass(torch.Tensor), db.as_subclass(torch.Tensor)
 
 
@@ -303,11 +367,13 @@ def basic_update_block_forward(weights, net, inp, corr, flow, prefix='update_blo
     return update_block_forward(weights, net, inp, corr, flow, prefix, 'raft')
 
 
-def update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update_block'):
+def update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update_block', defer=None):
     """Backward of ``update_block_forward``: upstream gradients of its outputs (``d_mask`` None for the small block) ->
     gradients w.r.t. the four inputs (``net``, ``inp``, ``corr``, ``flow``) and w.r.t. every kernel and bias of the block
     (dict under the weight names).  Every arithmetic step is a HIP kernel (convolution dgrad / wgrad, gate and relu backward,
-    axpby); torch only concatenates, slices and allocates."""
+    axpby); torch only concatenates, slices and allocates.
+    ``defer`` (a ``WgradDefer``): the kernel / bias gradients of the block's generic convolutions are left to it
+    (``deferred_update_grads`` turns its result into the same dict); only convf1's are returned here."""
     lib = _dev.lib()
     p = prefix
     s = saved
@@ -319,10 +385,10 @@ def update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update
     B, H, W, _ = d_net.shape
     n_h = d_net.numel()
 
-    def conv_b(name, x, dy, y=None, kernel=None):
+    def conv_b(name, x, dy, y=None, kernel=None, key=None):
         k = w[f'{p}/{name}/kernel'] if kernel is None else kernel
-        dx, dk, db = _conv_bwd(x, k, dy, y)
-        if kernel is None:
+        dx, dk, db = _conv_bwd(x, k, dy, y, defer=None if defer is None else (defer, key if key is not None else f'{p}/{name}'))
+        if kernel is None and defer is None:
             grads[f'{p}/{name}/kernel'], grads[f'{p}/{name}/bias'] = dk, db
         return dx, dk, db
 
@@ -351,9 +417,10 @@ def update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update
         kzr = _cached(w[f'{p}/gru/convz{g}/kernel'], 'kzr', lambda: _cat(
             [w[f'{p}/gru/convz{g}/kernel'], w[f'{p}/gru/convr{g}/kernel']], 3), also=w[f'{p}/gru/convr{g}/kernel'])
         d_zr = torch.cat([dz_pre, dr_pre], dim=-1).contiguous()
-        d_hx, dk, db = conv_b(None, s[f'hx{g}'], d_zr, kernel=kzr)
-        grads[f'{p}/gru/convz{g}/kernel'], grads[f'{p}/gru/convr{g}/kernel'] = dk[..., :hd].contiguous(), dk[..., hd:].contiguous()
-        grads[f'{p}/gru/convz{g}/bias'], grads[f'{p}/gru/convr{g}/bias'] = db[:hd].contiguous(), db[hd:].contiguous()
+        d_hx, dk, db = conv_b(None, s[f'hx{g}'], d_zr, kernel=kzr, key=('zr', p, g, hd))
+        if defer is None:
+            grads[f'{p}/gru/convz{g}/kernel'], grads[f'{p}/gru/convr{g}/kernel'] = dk[..., :hd].contiguous(), dk[..., hd:].contiguous()
+            grads[f'{p}/gru/convz{g}/bias'], grads[f'{p}/gru/convr{g}/bias'] = db[:hd].contiguous(), db[hd:].contiguous()
         dh = _axpby(1.0, dh_in, 1.0, d_hx[..., :hd].contiguous())
         dx_g = _axpby(1.0, dx_q, 1.0, d_hx[..., hd:].contiguous())
         dx_total = dx_g if dx_total is None else _axpby(1.0, dx_total, 1.0, dx_g)
@@ -385,6 +452,20 @@ def update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update
     d_flow = _axpby(1.0, d_flow_x, 1.0, d_flow_f)
     return {'net': _dev.wrap(dh), 'inp': _dev.wrap(d_inp), 'corr': _dev.wrap(d_corr), 'flow': _dev.wrap(d_flow)}, \
         {k: _dev.wrap(v) for k, v in grads.items()}
+
+
+def deferred_update_grads(defer):
+    """``WgradDefer.finish()`` of an update block's layers as the weight-name dict ``update_block_backward`` returns (the fused
+    z | r gradient split back into convz / convr)."""
+    grads = {}
+    for key, (dk, db) in defer.finish().items():
+        if isinstance(key, tuple) and key[0] == 'zr':
+            _, p, g, hd = key
+            grads[f'{p}/gru/convz{g}/kernel'], grads[f'{p}/gru/convr{g}/kernel'] = dk[..., :hd].contiguous(), dk[..., hd:].contiguous()
+            grads[f'{p}/gru/convz{g}/bias'], grads[f'{p}/gru/convr{g}/bias'] = db[:hd].contiguous(), db[hd:].contiguous()
+        else:
+            grads[f'{key}/kernel'], grads[f'{key}/bias'] = dk, db
+    return grads
 
 
 def basic_update_block_backward(weights, saved, d_net, d_mask, d_delta, prefix='update_block'):
@@ -503,11 +584,16 @@ def loop_forward(weights, corr_block, net0, inp, iters, prefix='update_block', v
     return preds, tape
 
 
-def loop_backward(weights, corr_block, tape, d_preds, prefix='update_block'):
+def loop_backward(weights, corr_block, tape, d_preds, prefix='update_block', defer_wgrad=None):
     """Backward through time of ``loop_forward`` for the upstream gradients ``d_preds`` of the flow predictions (e.g.
     ``sequence_loss_grad``).  The reference does not stop the gradient at ``coords1`` (model.py:93-106), so it flows
-    through the lookup coordinates of every iteration.  Returns ``(d_net0, d_inp, d_pyramid, weight_grads)``."""
+    through the lookup coordinates of every iteration.  Returns ``(d_net0, d_inp, d_pyramid, weight_grads)``.
+    ``defer_wgrad`` (default: on for an fp32 tape, off for a bf16 one, whose point is memory): the weight gradients of the
+    update block's convolutions are evaluated once over all iterations (``WgradDefer``) instead of per iteration."""
     iters = len(tape)
+    if defer_wgrad is None:
+        defer_wgrad = not any(isinstance(v, tuple) for v in tape[0]['saved'].values()) if iters else False
+    defer = WgradDefer() if defer_wgrad else None
     d_c = None          # gradient w.r.t. coords1 after the current iteration
     d_net = None
     d_inp = None
@@ -525,7 +611,7 @@ def loop_backward(weights, corr_block, tape, d_preds, prefix='update_block'):
         d_c = d_flowlow if d_c is None else _axpby(1.0, d_c, 1.0, d_flowlow)
         if d_net is None:
             d_net = torch.zeros_like(saved['net'])
-        din, dw = update_block_backward(weights, saved, d_net, d_mask, d_c, prefix)
+        din, dw = update_block_backward(weights, saved, d_net, d_mask, d_c, prefix, defer=defer)
         d_coords, d_pyr = corr_lookup_backward(corr_block, t['coords1'], din['corr'], d_pyramid=d_pyr)
         d_c = _axpby(1.0, d_c, 1.0, din['flow'].as_subclass(torch.Tensor))
         d_c = _axpby(1.0, d_c, 1.0, d_coords.as_subclass(torch.Tensor))
@@ -535,6 +621,8 @@ def loop_backward(weights, corr_block, tape, d_preds, prefix='update_block'):
             wg = {k: v.as_subclass(torch.Tensor) for k, v in dw.items()}
         else:
             wg = {k: _axpby(1.0, wg[k], 1.0, v.as_subclass(torch.Tensor).contiguous()) for k, v in dw.items()}
+    if defer is not None:
+        wg.update(deferred_update_grads(defer))
     return _dev.wrap(d_net), _dev.wrap(d_inp), d_pyr, {k: _dev.wrap(v) for k, v in wg.items()}
 
 
