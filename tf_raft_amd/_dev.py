@@ -10,10 +10,16 @@ import torch
 from . import _ffi
 
 
+_GPU_SEEN = False
+
+
 def require_gpu() -> torch.device:
-    if not torch.cuda.is_available():
-        raise RuntimeError('tf_raft_amd needs a ROCm GPU (MI355X / gfx950): no device is visible and '
-                           'there is no CPU fallback')
+    global _GPU_SEEN
+    if not _GPU_SEEN:                          # asked once: torch.cuda.is_available() costs ~8 us per call on ROCm
+        if not torch.cuda.is_available():
+            raise RuntimeError('tf_raft_amd needs a ROCm GPU (MI355X / gfx950): no device is visible and '
+                               'there is no CPU fallback')
+        _GPU_SEEN = True
     return torch.device('cuda', torch.cuda.current_device())
 
 
@@ -35,6 +41,8 @@ def wrap(t: torch.Tensor) -> torch.Tensor:
 
 def to_device(x, device=None, dtype=torch.float32) -> torch.Tensor:
     """numpy / torch (any device) -> contiguous device tensor of ``dtype``."""
+    if isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == dtype and device is None and x.is_contiguous():
+        return x.detach().as_subclass(torch.Tensor)      # already where and what it should be (the training path: thousands of calls per step)
     device = device or require_gpu()
     if isinstance(x, torch.Tensor):
         t = x.detach().as_subclass(torch.Tensor)

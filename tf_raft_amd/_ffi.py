@@ -151,6 +151,8 @@ def load_library():
     makes that a no-op for an up-to-date .so), so a stale library never meets newer struct mirrors; without hipcc the
     prebuilt .so is used as is.  Either way ``raft_version()`` must equal ``ABI_VERSION``."""
     global _LIB
+    if _LIB is not None:                       # fast path: no lock once loaded
+        return _LIB
     with _LOCK:
         if _LIB is not None:
             return _LIB

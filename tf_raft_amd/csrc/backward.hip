@@ -246,6 +246,7 @@ constexpr int WG_TH = 4, WG_TW = 16, WG_PS = 80, WG_MAXT = 9, WG_MAXSEG = 32;
 struct WgradArgs {
     const float *x[WG_MAXSEG], *dy[WG_MAXSEG];
     float *part;          // [S][T][cin][cout]
+    float *bias_part;     // [S][cout] column sums of dy per slice (written by the workgroups of input-channel block 0), or NULL
     int ldx, ldy, cin, cout, B, H, W, kh, kw, S, tiles_y, tiles_x, nseg, tiles_seg;
 };
 
@@ -297,6 +298,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
                 ry[i] = *(const f32x4 *)(ds + ((int64_t)(b * p.H + yy) * p.W + xx) * p.ldy + c);
         }
     };
+    // bias gradient = column sums of dy: the dy tile is in LDS anyway -- the workgroups of input-channel block 0 add it up
+    // (thread = channel tid & 63 over the 16 pixels tid >> 6 of every tile), instead of a second pass over dy
+    const bool do_bias = p.bias_part != nullptr && cib == 0;     // workgroup-uniform
+    float bsum = 0.f;
     if (t_lo < t_hi) fetch(t_lo);
     for (int tile = t_lo; tile < t_hi; ++tile) {
         __syncthreads();                                   // previous tile's fragments have been read
@@ -309,6 +314,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
         for (int i = 0; i < NY; ++i) *(f32x4 *)(sY + ((tid + 256 * i) >> 4) * WG_PS + c4 * 4) = ry[i];
         __syncthreads();
         if (tile + 1 < t_hi) fetch(tile + 1);
+        if (do_bias) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) bsum += sY[((tid >> 6) * 16 + q) * WG_PS + (tid & 63)];
+        }
         // k-steps: 4 consecutive pixels of a tile row; lane (r, g): pixel 4 * step + g
 #pragma unroll 2
         for (int step = 0; step < WG_TH * WG_TW / 4; ++step) {
@@ -336,6 +345,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
                 if (ci < p.cin && co < p.cout)
                     p.part[(((int64_t)sl * T + t) * p.cin + ci) * p.cout + co] = acc[t][j][e];
             }
+    if (do_bias) {
+        __syncthreads();
+        sY[tid] = bsum;
+        __syncthreads();
+        const int co = co0 + tid;
+        if (tid < 64 && co < p.cout) p.bias_part[(int64_t)sl * p.cout + co] = (sY[tid] + sY[64 + tid]) + (sY[128 + tid] + sY[192 + tid]);
+    }
 }
 
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int S, int64_t n, float *__restrict__ out) {
@@ -405,18 +421,18 @@ static int wgrad_launch(const float *const *xs, const float *const *dys, int nse
     RAFT_REQUIRE(cin % 4 == 0 && cout % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, RAFT_E_UNSUPPORTED);
     hipStream_t s = (hipStream_t)stream;
     WgradArgs a = {};
-    BiasGradArgs ba = {};
     for (int i = 0; i < nseg; ++i) {
         RAFT_REQUIRE_PTR(xs[i]);
         RAFT_REQUIRE_PTR(dys[i]);
         RAFT_REQUIRE(raft_aligned16(xs[i]) && raft_aligned16(dys[i]), RAFT_E_ALIGN);
         a.x[i] = xs[i];
         a.dy[i] = dys[i];
-        ba.dy[i] = dys[i];
     }
     a.part = workspace;
-    a.ldx = ldx; a.ldy = ldy; a.cin = cin; a.cout = cout; a.B = B; a.H = H; a.W = W; a.kh = kh; a.kw = kw;
+    const int64_t n = (int64_t)kh * kw * cin * cout;
     a.S = wgrad_slices(cin, cout, B * nseg, H, W);
+    a.bias_part = d_bias ? workspace + (int64_t)a.S * n : nullptr;
+    a.ldx = ldx; a.ldy = ldy; a.cin = cin; a.cout = cout; a.B = B; a.H = H; a.W = W; a.kh = kh; a.kw = kw;
     a.tiles_y = (H + WG_TH - 1) / WG_TH;
     a.tiles_x = (W + WG_TW - 1) / WG_TW;
     a.nseg = nseg;
@@ -433,16 +449,10 @@ static int wgrad_launch(const float *const *xs, const float *const *dys, int nse
     else
         return RAFT_E_UNSUPPORTED;
     RAFT_TRY(raft_launch_status());
-    const int64_t n = (int64_t)kh * kw * cin * cout;
     wgrad_reduce_kernel<<<raft_ceil_div(n, 256), 256, 0, s>>>(workspace, a.S, n, d_kernel);
     RAFT_TRY(raft_launch_status());
     if (d_bias) {
-        float *bp = workspace + (int64_t)a.S * n;
-        ba.Mseg = (int64_t)B * H * W;
-        ba.nseg = nseg; ba.ldy = ldy; ba.cout = cout; ba.nblk = BIAS_BLOCKS; ba.part = bp;
-        bias_grad_partial_kernel<<<BIAS_BLOCKS, 256, 0, s>>>(ba);
-        RAFT_TRY(raft_launch_status());
-        wgrad_reduce_kernel<<<raft_ceil_div(cout, 256), 256, 0, s>>>(bp, BIAS_BLOCKS, cout, d_bias);
+        wgrad_reduce_kernel<<<raft_ceil_div(cout, 256), 256, 0, s>>>(a.bias_part, a.S, cout, d_bias);
         RAFT_TRY(raft_launch_status());
     }
     return RAFT_OK;

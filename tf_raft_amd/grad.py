@@ -19,6 +19,8 @@ from ._ffi import check
 
 
 def _f32(t):
+    if type(t) is torch.Tensor and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+        return t
     return _dev.to_device(t).as_subclass(torch.Tensor).to(torch.float32).contiguous()
 
 
