@@ -14,6 +14,23 @@ from conftest import report
 
 pytestmark = pytest.mark.gpu
 
+WINOGRAD_TESTS = ('test_training_convolutions_on_winograd_match_the_direct_kernels', 'test_full_train_step_matches_reference_semantics',
+                  'test_train_step_runs_device_resident_with_dropout_and_bf16_tape')
+
+
+@pytest.fixture(autouse=True)
+def _train_conv_algorithm(request):
+    """The per-operator tolerances of this file are those of the DIRECT fp32 kernels (a convolution's rounding error is then a
+    plain fp32 dot product's): they run with grad.TRAIN_WINOGRAD off.  The tests named in WINOGRAD_TESTS run the product default
+    (F(2x2, 3x3) / F(4, 5) forward and input-gradient convolutions) against bounds that include the Winograd noise."""
+    from tf_raft_amd import grad
+    old = grad.TRAIN_WINOGRAD
+    grad.TRAIN_WINOGRAD = request.node.name.split('[')[0] in WINOGRAD_TESTS
+    grad.clear_pack_cache()
+    yield
+    grad.TRAIN_WINOGRAD = old
+    grad.clear_pack_cache()
+
 
 def _np(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
@@ -305,6 +322,48 @@ def test_loop_backward_through_time_matches_autograd(rng):
         worst_d = max(worst_d, float(np.linalg.norm(a - b_) / max(np.linalg.norm(b_), 1e-30)))
     report('deferred vs per-iteration weight gradients', worst_rel_l2=worst_d)
     assert worst_d <= 2e-5
+
+
+def test_training_convolutions_on_winograd_match_the_direct_kernels(rng):
+    """grad.TRAIN_WINOGRAD (default on): one BasicUpdateBlock call forward + backward with the 3x3 / 1x5 / 5x1 layers on the
+    F(2x2, 3x3) / F(4, 5) kernels against the same call on the direct kernels -- outputs, input gradients and all 30 weight
+    gradients within 2e-5 of the tensor's scale (the direct path itself is within 1.2e-6 of float64 autograd), with NumPy and with
+    device-resident parameters (the transforms G g G^T / G' g are then evaluated on the device)."""
+    from tf_raft_amd import grad, _dev
+    from tf_raft_amd import weights as wm
+    B, h, w = 2, 14, 22
+    wts = {k: v for k, v in wm.condition_weights('raft', wm.init_weights('raft', seed=3)).items() if k.startswith('update_block')}
+    net = np.tanh(rng.normal(size=(B, h, w, 128))).astype(np.float32)
+    inp = np.maximum(rng.normal(size=(B, h, w, 128)), 0).astype(np.float32)
+    corr = rng.normal(size=(B, h, w, 324)).astype(np.float32)
+    flow = rng.normal(size=(B, h, w, 2)).astype(np.float32)
+    d_net = rng.normal(size=(B, h, w, 128)).astype(np.float32)
+    d_mask = rng.normal(size=(B, h, w, 576)).astype(np.float32)
+    d_delta = rng.normal(size=(B, h, w, 2)).astype(np.float32)
+
+    def run(params):
+        grad.clear_pack_cache()
+        n, m, d, saved = grad.basic_update_block_forward(params, net, inp, corr, flow)
+        din, dw = grad.basic_update_block_backward(params, saved, d_net, d_mask, d_delta)
+        return [_np(n), _np(m), _np(d)], {k: _np(v) for k, v in din.items()}, {k: _np(v) for k, v in dw.items()}
+
+    assert grad.TRAIN_WINOGRAD
+    got = run(wts)
+    got_dev = run({k: _dev.to_device(v) for k, v in wts.items()})
+    grad.TRAIN_WINOGRAD = False
+    want = run(wts)
+    worst = 0.0
+    for label, g in (('host parameters', got), ('device parameters', got_dev)):
+        for a, b_ in zip(g[0], want[0]):
+            worst = max(worst, float(np.abs(a - b_).max() / np.abs(b_).max()))
+        for part in (1, 2):
+            assert sorted(g[part]) == sorted(want[part])
+            for k in want[part]:
+                worst = max(worst, float(np.abs(g[part][k] - want[part][k]).max() / max(np.abs(want[part][k]).max(), 1e-30)))
+        report(f'training convolutions on Winograd vs direct ({label})', worst_rel=worst)
+    for k in want[2]:   # the two parameter homes run the same kernels on the same packed bits
+        np.testing.assert_allclose(got[2][k], got_dev[2][k], rtol=0, atol=1e-6 * max(np.abs(want[2][k]).max(), 1e-30))
+    assert worst <= 2e-5
 
 
 def test_conv2d_wgrad_multi_is_the_sum_of_the_single_gradients(rng):

@@ -91,6 +91,49 @@ def _pack_conv_any(kernel, bias, sources):
     return wp, b, npad
 
 
+# The training forward and the input gradients run the 3x3 / 1x5 / 5x1 layers on the Winograd kernels of the inference path
+# (F(2x2, 3x3): 2.25x fewer multiplies, F(4, 5): 2.5x) -- fp32 throughout, deviation from the direct kernel ~1e-6 relative per
+# layer (tests/test_gpu_kernels.py).  False = the direct kernels everywhere (the parity tests check both).
+TRAIN_WINOGRAD = True
+
+
+def _wino_kind(kh, kw):
+    if not TRAIN_WINOGRAD:
+        return None
+    return '2d' if (kh, kw) == (3, 3) else ('1d' if (kh, kw) in ((1, 5), (5, 1)) else None)
+
+
+def _wino_transform_any(kernel):
+    """G g G^T (3x3 -> 4x4 taps, F(2x2, 3x3)) or G' g (1x5 / 5x1 -> 8 taps, F(4, 5)) where the parameter lives; float64, one
+    rounding (packing.winograd_kernel / winograd1d_kernel)."""
+    kh, kw = kernel.shape[:2]
+    if not _is_t(kernel):
+        return packing.winograd_kernel(kernel) if (kh, kw) == (3, 3) else packing.winograd1d_kernel(kernel, 4)
+    k = kernel.to(torch.float64)
+    if (kh, kw) == (3, 3):
+        g = torch.as_tensor(packing._WINO_G, dtype=torch.float64, device=kernel.device)
+        return torch.einsum('au,bv,uvio->abio', g, g, k).to(torch.float32).contiguous()
+    g = torch.as_tensor(packing._WINO1D4_G, dtype=torch.float64, device=kernel.device)
+    return torch.einsum('tk,kio->tio', g, k[0] if kh == 1 else k[:, 0]).to(torch.float32)[:, None].contiguous()
+
+
+def _conv_launch(x, cpad, kernel_shape, wino, wp_d, b_d, npad, nvalid, act, scale, out, what):
+    """One stride-1 'same' convolution of the (B, H, W, cpad) tensor ``x`` through the direct or the Winograd entry point."""
+    kh, kw = kernel_shape
+    B, H, W, _ = x.shape
+    lib = _dev.lib()
+    if wino == '2d':
+        rc = lib.raft_conv2d_winograd_f32(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, npad, nvalid,
+                                          act, float(scale), _dev.ptr(out), nvalid, _dev.stream_ptr())
+    elif wino == '1d':
+        rc = lib.raft_conv1d_winograd4_f32(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw, npad,
+                                           nvalid, act, float(scale), _dev.ptr(out), nvalid, _dev.stream_ptr())
+    else:
+        rc = lib.raft_conv2d_f32(_dev.ptr(x), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw, npad, nvalid,
+                                 act, float(scale), _dev.ptr(out), nvalid, _dev.stream_ptr())
+    check(rc, what)
+
+
 def _dgrad_kernel_any(kernel):
     """``packing.dgrad_kernel``: spatial flip, in / out channels transposed."""
     if not _is_t(kernel):
@@ -227,14 +270,18 @@ def conv2d_backward(x, kernel, dy, y=None, defer=None):
     # input gradient: the forward convolution of dy with the flipped, transposed kernel
     cpad = packing.round_up(cout, 32)
 
-    wp_d, b_d, npad = _cached(kernel, 'dgrad', lambda: _pack_conv_any(_dgrad_kernel_any(kernel), None, [(cout, cpad)]))
+    wino = _wino_kind(kh, kw)
+
+    def make_d():
+        kd = _dgrad_kernel_any(kernel)
+        return _pack_conv_any(_wino_transform_any(kd) if wino else kd, None, [(cout, cpad)])
+    wp_d, b_d, npad = _cached(kernel, 'dgrad' + (wino or ''), make_d)
     dyp = dy
     if cpad != cout:
         dyp = torch.zeros((B, H, W, cpad), device=x.device, dtype=torch.float32)
         dyp[..., :cout] = dy
     dx = torch.empty((B, H, W, cin), device=x.device, dtype=torch.float32)
-    check(lib.raft_conv2d_f32(_dev.ptr(dyp), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw, npad,
-                              cin, 0, 1.0, _dev.ptr(dx), cin, _dev.stream_ptr()), 'conv2d dgrad')
+    _conv_launch(dyp, cpad, (kh, kw), wino, wp_d, b_d, npad, cin, 0, 1.0, dx, 'conv2d dgrad')
     if defer is not None:
         return _dev.wrap(dx), None, None
     return _dev.wrap(dx), _dev.wrap(d_kernel), _dev.wrap(d_bias)
@@ -250,15 +297,15 @@ def _conv_fwd(x, kernel, bias, act=0, scale=1.0):
     kh, kw, cin, cout = kernel.shape
     B, H, W, c = x.shape
     cpad = packing.round_up(cin, 32)
-    make = lambda: _pack_conv_any(kernel, bias, [(cin, cpad)])
-    wp_d, b_d, npad = _cached(kernel, 'fwd', make, also=bias) if isinstance(bias, (np.ndarray, torch.Tensor)) else make()
+    wino = _wino_kind(kh, kw)
+    make = lambda: _pack_conv_any(_wino_transform_any(kernel) if wino else kernel, bias, [(cin, cpad)])
+    wp_d, b_d, npad = _cached(kernel, 'fwd' + (wino or ''), make, also=bias) if isinstance(bias, (np.ndarray, torch.Tensor)) else make()
     xp = x
     if cpad != c:
         xp = torch.zeros((B, H, W, cpad), device=x.device, dtype=torch.float32)
         xp[..., :c] = x
     out = torch.empty((B, H, W, cout), device=x.device, dtype=torch.float32)
-    check(_dev.lib().raft_conv2d_f32(_dev.ptr(xp), cpad, cpad, None, 0, 0, _dev.ptr(wp_d), _dev.ptr(b_d), B, H, W, kh, kw, npad,
-                                     cout, act, float(scale), _dev.ptr(out), cout, _dev.stream_ptr()), 'conv2d')
+    _conv_launch(xp, cpad, (kh, kw), wino, wp_d, b_d, npad, cout, act, scale, out, 'conv2d')
     return out
 
 

@@ -25,7 +25,7 @@ i1 = rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32)
 i2 = rng.uniform(0, 255, (B, H, W, 3)).astype(np.float32)
 flow = (rng.normal(size=(B, H, W, 2)) * 3).astype(np.float32)
 valid = np.ones((B, H, W), bool)
-for step in range(4):
+for step in range(int(os.environ.get("TRAIN_PROBE_STEPS", "8"))):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     res = model.train_step((i1, i2, flow, valid))
