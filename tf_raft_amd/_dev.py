@@ -58,7 +58,13 @@ def ptr(t: torch.Tensor) -> int:
 
 
 def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's CURRENT stream on the current device (honours ``torch.cuda.stream(...)`` contexts).  Through the
+    C binding directly: ``torch.cuda.current_stream().cuda_stream`` costs ~9 us per call (device-index resolution in Python), and
+    a training step asks 5000 times."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:                      # another torch build: the public route
+        return torch.cuda.current_stream().cuda_stream
 
 
 def i64_array(values):

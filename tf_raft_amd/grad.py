@@ -103,6 +103,17 @@ def _wino_kind(kh, kw):
     return '2d' if (kh, kw) == (3, 3) else ('1d' if (kh, kw) in ((1, 5), (5, 1)) else None)
 
 
+_WINO_G_DEV = {}
+
+
+def _wino_g(name, device):
+    """The transform matrices G (float64) on the device, uploaded once (an upload per use would be a blocking copy per layer)."""
+    key = (name, str(device))
+    if key not in _WINO_G_DEV:
+        _WINO_G_DEV[key] = torch.as_tensor(getattr(packing, name), dtype=torch.float64, device=device)
+    return _WINO_G_DEV[key]
+
+
 def _wino_transform_any(kernel):
     """G g G^T (3x3 -> 4x4 taps, F(2x2, 3x3)) or G' g (1x5 / 5x1 -> 8 taps, F(4, 5)) where the parameter lives; float64, one
     rounding (packing.winograd_kernel / winograd1d_kernel)."""
@@ -111,9 +122,9 @@ def _wino_transform_any(kernel):
         return packing.winograd_kernel(kernel) if (kh, kw) == (3, 3) else packing.winograd1d_kernel(kernel, 4)
     k = kernel.to(torch.float64)
     if (kh, kw) == (3, 3):
-        g = torch.as_tensor(packing._WINO_G, dtype=torch.float64, device=kernel.device)
+        g = _wino_g('_WINO_G', kernel.device)
         return torch.einsum('au,bv,uvio->abio', g, g, k).to(torch.float32).contiguous()
-    g = torch.as_tensor(packing._WINO1D4_G, dtype=torch.float64, device=kernel.device)
+    g = _wino_g('_WINO1D4_G', kernel.device)
     return torch.einsum('tk,kio->tio', g, k[0] if kh == 1 else k[:, 0]).to(torch.float32)[:, None].contiguous()
 
 
