@@ -128,8 +128,17 @@ class Mean:
         self.count = 0
 
     def update_state(self, value):
-        self.total += float(value)
+        # a device scalar stays on the device (no host synchronisation inside a training step: the caller converts the result
+        # when it wants the number, as with the Keras metric's tensor)
+        if isinstance(value, torch.Tensor) and value.is_cuda:
+            v = value.detach().as_subclass(torch.Tensor).to(torch.float32).reshape(())
+            self.total = v.clone() if self.count == 0 else self.total + v
+        else:
+            self.total = self.total + float(value)
         self.count += 1
 
     def result(self):
-        return self.total / self.count if self.count else 0.0       # keras: divide_no_nan
+        if not self.count:
+            return 0.0                                              # keras: divide_no_nan
+        mean = self.total / self.count
+        return _dev.wrap(mean) if isinstance(mean, torch.Tensor) else mean

@@ -421,6 +421,10 @@ class RAFT:
         image1, image2, flow, valid = data
         image1 = _dev.to_device(image1).as_subclass(torch.Tensor).to(torch.float32)
         image2 = _dev.to_device(image2).as_subclass(torch.Tensor).to(torch.float32)
+        # the ground truth goes to the device NOW: an upload from pageable host memory waits for everything already queued on
+        # the stream, and in front of the loss that is the whole forward pass (the host would enqueue the backward only after
+        # the GPU had drained: 20 ms of a 85 ms step)
+        flow, valid = losses._truth((flow, valid))
         B, H, W, _ = image1.shape
         if H % 8 or W % 8:
             raise ValueError(f'H and W must be multiples of 8 (got {H}x{W})')
