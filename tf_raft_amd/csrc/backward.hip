@@ -298,10 +298,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
                 ry[i] = *(const f32x4 *)(ds + ((int64_t)(b * p.H + yy) * p.W + xx) * p.ldy + c);
         }
     };
-    // bias gradient = column sums of dy: the dy tile is in LDS anyway -- the workgroups of input-channel block 0 add it up
-    // (thread = channel tid & 63 over the 16 pixels tid >> 6 of every tile), instead of a second pass over dy
+    // bias gradient = column sums of dy: the workgroups of input-channel block 0 add up the dy items they stage anyway (a
+    // thread's items all belong to channel quad tid & 15: four vector adds per tile, joined once at the end), instead of a
+    // second pass over dy
     const bool do_bias = p.bias_part != nullptr && cib == 0;     // workgroup-uniform
-    float bsum = 0.f;
+    f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
     if (t_lo < t_hi) fetch(t_lo);
     for (int tile = t_lo; tile < t_hi; ++tile) {
         __syncthreads();                                   // previous tile's fragments have been read
@@ -312,12 +313,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < NY; ++i) *(f32x4 *)(sY + ((tid + 256 * i) >> 4) * WG_PS + c4 * 4) = ry[i];
-        __syncthreads();
-        if (tile + 1 < t_hi) fetch(tile + 1);
         if (do_bias) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) bsum += sY[((tid >> 6) * 16 + q) * WG_PS + (tid & 63)];
+            for (int i = 0; i < NY; ++i) bacc += ry[i];
         }
+        __syncthreads();
+        if (tile + 1 < t_hi) fetch(tile + 1);
         // k-steps: 4 consecutive pixels of a tile row; lane (r, g): pixel 4 * step + g
 #pragma unroll 2
         for (int step = 0; step < WG_TH * WG_TW / 4; ++step) {
@@ -347,10 +348,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
             }
     if (do_bias) {
         __syncthreads();
-        sY[tid] = bsum;
+        *(f32x4 *)(sY + tid * 4) = bacc;                  // [pixel group tid >> 4][channel quad tid & 15][4]
         __syncthreads();
         const int co = co0 + tid;
-        if (tid < 64 && co < p.cout) p.bias_part[(int64_t)sl * p.cout + co] = (sY[tid] + sY[64 + tid]) + (sY[128 + tid] + sY[192 + tid]);
+        if (tid < 64 && co < p.cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int gq = 0; gq < 16; ++gq) t += sY[(gq * 16 + (tid >> 2)) * 4 + (tid & 3)];
+            p.bias_part[(int64_t)sl * p.cout + co] = t;
+        }
     }
 }
 
@@ -398,10 +404,11 @@ int wgrad_slices(int cin, int cout, int B, int H, int W) {
     const int blocks = ((cin + 63) / 64) * ((cout + 63) / 64);
     int S = (512 + blocks - 1) / blocks;                   // about two workgroups per CU: every slice costs a pass of the
     if (S > ntiles) S = ntiles;                            // ordered second-stage sum over the whole kernel gradient
-    if (S > 64) S = 64;
+    // (no cap below that: the 64 -> 64 layers of the encoders are ONE channel block, and 64 slices were 64 workgroups for 256 CUs
+    // -- 1.4 ms per launch at the training crop; 512 slices of 147 KB cost the second stage 15 us)
     return S < 1 ? 1 : S;
 }
-constexpr int BIAS_BLOCKS = 256;
+constexpr int BIAS_BLOCKS = 512;   // >= the largest slice count: the per-slice column sums of dy live behind the kernel partials
 }   // namespace
 
 extern "C" int64_t raft_conv2d_wgrad_workspace_floats(int cin, int cout, int B, int H, int W, int kh, int kw) {
