@@ -360,12 +360,29 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
     }
 }
 
+// out[i] = sum over the S slices of part[k][i], in a fixed order: thread = (element blockIdx.x * 64 + tid % 64, quarter tid / 64 of
+// the slices), eight independent loads in flight per thread, the quarters joined through LDS (one thread per element walking
+// all slices with dependent adds was latency-bound: 49 us per call with 512 slices)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int S, int64_t n, float *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float sh[4][64];
+    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + el;
+    const int per = (S + 3) / 4, k0 = sg * per, k1 = (k0 + per < S) ? k0 + per : S;
     float s = 0.f;
-    for (int k = 0; k < S; ++k) s += part[(int64_t)k * n + i];
-    out[i] = s;
+    if (i < n) {
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(k + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < k1; ++k) s += part[(int64_t)k * n + i];
+    }
+    sh[sg][el] = s;
+    __syncthreads();
+    if (sg == 0 && i < n) out[i] = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
 }
 
 // column sums of dy: partial[blk][co] over a pixel range, then the same ordered reduction.  Thread = (pixel lane tid / 64,
@@ -456,10 +473,10 @@ static int wgrad_launch(const float *const *xs, const float *const *dys, int nse
     else
         return RAFT_E_UNSUPPORTED;
     RAFT_TRY(raft_launch_status());
-    wgrad_reduce_kernel<<<raft_ceil_div(n, 256), 256, 0, s>>>(workspace, a.S, n, d_kernel);
+    wgrad_reduce_kernel<<<raft_ceil_div(n, 64), 256, 0, s>>>(workspace, a.S, n, d_kernel);
     RAFT_TRY(raft_launch_status());
     if (d_bias) {
-        wgrad_reduce_kernel<<<raft_ceil_div(cout, 256), 256, 0, s>>>(a.bias_part, a.S, cout, d_bias);
+        wgrad_reduce_kernel<<<raft_ceil_div(cout, 64), 256, 0, s>>>(a.bias_part, a.S, cout, d_bias);
         RAFT_TRY(raft_launch_status());
     }
     return RAFT_OK;
@@ -667,7 +684,7 @@ extern "C" int raft_conv7x7_c2_backward_f32(const float *flow, const float *dy, 
         conv7x7_c2_wgrad_partial_kernel<64><<<C7_SLICES, 256, 0, s>>>(flow, dy, ldy, B, H, W, workspace);
     }
     RAFT_TRY(raft_launch_status());
-    wgrad_reduce_kernel<<<raft_ceil_div(98 * cout, 256), 256, 0, s>>>(workspace, C7_SLICES, (int64_t)98 * cout, d_kernel);
+    wgrad_reduce_kernel<<<raft_ceil_div(98 * cout, 64), 256, 0, s>>>(workspace, C7_SLICES, (int64_t)98 * cout, d_kernel);
     float *bp = workspace + (int64_t)C7_SLICES * 98 * cout;
     {
         BiasGradArgs ba = {};
@@ -675,7 +692,7 @@ extern "C" int raft_conv7x7_c2_backward_f32(const float *flow, const float *dy, 
         ba.Mseg = M; ba.nseg = 1; ba.ldy = ldy; ba.cout = cout; ba.nblk = C7_SLICES; ba.part = bp;
         bias_grad_partial_kernel<<<C7_SLICES, 256, 0, s>>>(ba);
     }
-    wgrad_reduce_kernel<<<raft_ceil_div(cout, 256), 256, 0, s>>>(bp, C7_SLICES, cout, d_bias);
+    wgrad_reduce_kernel<<<raft_ceil_div(cout, 64), 256, 0, s>>>(bp, C7_SLICES, cout, d_bias);
     return raft_launch_status();
 }
 
@@ -1079,6 +1096,7 @@ __global__ void __launch_bounds__(256) norm_stats_final_kernel(const double2 *__
     if (i >= G * C) return;
     const int g = i / C, c = i - g * C;
     double a = 0.0, b = 0.0;
+#pragma unroll 8
     for (int s = 0; s < NORM_SLICES; ++s) {
         const double2 t = part[((int64_t)g * NORM_SLICES + s) * C + c];
         a += t.x;
@@ -1106,22 +1124,39 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float *__restrict
 // sums[(g * C + c)] = {sum dy, sum dy xhat} over the group (ordered over slices); dgamma / dbeta over the groups
 __global__ void __launch_bounds__(256) norm_bwd_final_kernel(const double2 *__restrict__ part, int G, int C, double2 *__restrict__ sums,
                                                              float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    // thread = (channel blockIdx.x * 64 + tid % 64, quarter tid / 64 of the slices): independent loads in flight, the four
+    // quarters joined through LDS in fixed order (one thread per channel walking G x NORM_SLICES records took 85 us per call)
+    static_assert(NORM_SLICES % 4 == 0, "slice quarters");
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double tg = 0.0, tb = 0.0;
     for (int g = 0; g < G; ++g) {
         double a = 0.0, b = 0.0;
-        for (int s = 0; s < NORM_SLICES; ++s) {
-            const double2 t = part[((int64_t)g * NORM_SLICES + s) * C + c];
-            a += t.x;
-            b += t.y;
+        if (c < C) {
+#pragma unroll 8
+            for (int s = sg * (NORM_SLICES / 4); s < (sg + 1) * (NORM_SLICES / 4); ++s) {
+                const double2 t = part[((int64_t)g * NORM_SLICES + s) * C + c];
+                a += t.x;
+                b += t.y;
+            }
         }
-        sums[(int64_t)g * C + c] = make_double2(a, b);
-        tb += a;
-        tg += b;
+        sh[0][sg][cl] = a;
+        sh[1][sg][cl] = b;
+        __syncthreads();
+        if (sg == 0 && c < C) {
+            a = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+            b = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+            sums[(int64_t)g * C + c] = make_double2(a, b);
+            tb += a;
+            tg += b;
+        }
+        __syncthreads();
     }
-    dgamma[c] = (float)tg;
-    dbeta[c] = (float)tb;
+    if (sg == 0 && c < C) {
+        dgamma[c] = (float)tg;
+        dbeta[c] = (float)tb;
+    }
 }
 
 __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mean,
@@ -1164,7 +1199,7 @@ extern "C" int raft_norm_backward_f32(const float *x, const float *dy, const flo
     double2 *part = (double2 *)workspace, *sums = part + (int64_t)NORM_SLICES * G * C;
     norm_partial_kernel<<<G * NORM_SLICES, 256, 0, s>>>(x, dy, mean, rstd, P, C, 1, part);
     RAFT_TRY(raft_launch_status());
-    norm_bwd_final_kernel<<<raft_ceil_div(C, 256), 256, 0, s>>>(part, G, C, sums, dgamma, dbeta);
+    norm_bwd_final_kernel<<<raft_ceil_div(C, 64), 256, 0, s>>>(part, G, C, sums, dgamma, dbeta);
     RAFT_TRY(raft_launch_status());
     const int64_t total = (int64_t)G * P * C;
     norm_bwd_dx_kernel<<<raft_ceil_div(total, 256), 256, 0, s>>>(x, dy, mean, rstd, gamma, sums, P, C, 1.0 / (double)P, total, dx);
