@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 213          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 214          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -524,6 +524,15 @@ int raft_sumsq_f32(const float *x, int64_t n, int accumulate, double *out, doubl
  * m, v Adam moments; var -= lr_t * m / (sqrt(v) + epsilon) with lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) from the caller. */
 int raft_adamw_step_f32(float *var, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1, float beta2,
                         float epsilon, float weight_decay, const double *global_norm_sq, float clip_norm, void *stream);
+/* The same two steps over MANY tensors per launch (host arrays of device pointers and element counts, copied into the kernel
+ * arguments in chunks of 64): a RAFT model has 154 trainable tensors, i.e. 154 x 3 launches per training step otherwise.
+ * raft_sumsq_multi_f32: *out = sum over all tensors of the sum of squares (float64, ordered: deterministic), workspace
+ * raft_sumsq_multi_workspace_doubles(count) doubles.  raft_adamw_step_multi_f32: raft_adamw_step_f32's arithmetic per element. */
+int64_t raft_sumsq_multi_workspace_doubles(int count);
+int raft_sumsq_multi_f32(const float *const *xs, const int64_t *ns, int count, double *out, double *workspace, void *stream);
+int raft_adamw_step_multi_f32(float *const *vars, const float *const *grads, float *const *ms, float *const *vs, const int64_t *ns,
+                              int count, float lr_t, float beta1, float beta2, float epsilon, float weight_decay,
+                              const double *global_norm_sq, float clip_norm, void *stream);
 
 /* ---- backward of the volume build and of the state preparation */
 

@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 213     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 214     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -97,6 +97,10 @@ _SIGNATURES = {
     'raft_sumsq_workspace_doubles': (C.c_int64, []),
     'raft_sumsq_f32': (_I, [_P, C.c_int64, _I, _P, _P, _P]),
     'raft_adamw_step_f32': (_I, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_float, _P]),
+    'raft_sumsq_multi_workspace_doubles': (C.c_int64, [_I]),
+    'raft_sumsq_multi_f32': (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _I, _P, _P, _P]),
+    'raft_adamw_step_multi_f32': (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_int64), _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_float, _P]),
     'raft_gemm_f32': (_I, [_P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64, _I, _I, _I, _I, _I,
                           C.c_float, C.c_float, _P]),
     'raft_corr_build_backward_f32': (_I, [_P, _P, _P, c_i64_p, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

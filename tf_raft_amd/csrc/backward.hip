@@ -844,7 +844,104 @@ __global__ void __launch_bounds__(256) adamw_kernel(float *__restrict__ var, con
 }
 }   // namespace
 
+// ---- the same two steps over MANY tensors per launch (a model has 154 trainable tensors: 154 x 3 launches per step otherwise).
+// Up to MT_MAX tensors travel in the kernel arguments; blockIdx.y = tensor, blockIdx.x = one of MT_BLOCKS strided workgroups.
+constexpr int MT_MAX = 64, MT_BLOCKS = 16;
+struct MultiTensorArgs {
+    float *p[MT_MAX];             // var (adamw) / x (sumsq)
+    const float *g[MT_MAX];       // grad
+    float *m[MT_MAX], *v[MT_MAX];
+    int64_t n[MT_MAX];
+    int count;
+};
+__global__ void __launch_bounds__(256) sumsq_multi_partial_kernel(MultiTensorArgs a, double *__restrict__ part) {
+    const int t = blockIdx.y;
+    const float *x = a.p[t];
+    const int64_t n = a.n[t];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)MT_BLOCKS * 256) {
+        const double v = (double)x[i];
+        acc += v * v;
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(int64_t)t * MT_BLOCKS + blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(256) adamw_multi_kernel(MultiTensorArgs a, float lr_t, float b1, float b2, float eps, float wd,
+                                                          const double *__restrict__ gnorm_sq, float clip_norm) {
+    const int t = blockIdx.y;
+    float *var = a.p[t], *m = a.m[t], *v = a.v[t];
+    const float *grad = a.g[t];
+    const int64_t n = a.n[t];
+    float scale = 1.0f;
+    if (gnorm_sq) scale = clip_norm / fmaxf((float)sqrt(gnorm_sq[0]), clip_norm);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float g = grad[i] * scale;   // the arithmetic of adamw_kernel, statement for statement
+        float w = var[i];
+        w -= wd * w;
+        const float mi = b1 * m[i] + (1.0f - b1) * g;
+        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        var[i] = w - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
 extern "C" int64_t raft_sumsq_workspace_doubles(void) { return SUMSQ_WGS; }
+
+// Sum of squares over `count` tensors (host arrays of device pointers / element counts): float64, deterministic (per-tensor,
+// per-workgroup partials in `workspace` -- count * 16 doubles -- then ONE ordered final sum).  *out is overwritten.
+extern "C" int64_t raft_sumsq_multi_workspace_doubles(int count) { return count > 0 ? (int64_t)count * MT_BLOCKS : 0; }
+extern "C" int raft_sumsq_multi_f32(const float *const *xs, const int64_t *ns, int count, double *out, double *workspace, void *stream) {
+    RAFT_REQUIRE_PTR(xs); RAFT_REQUIRE_PTR(ns); RAFT_REQUIRE_PTR(out); RAFT_REQUIRE_PTR(workspace);
+    RAFT_REQUIRE(count > 0, RAFT_E_SHAPE);
+    hipStream_t s = (hipStream_t)stream;
+    for (int lo = 0; lo < count; lo += MT_MAX) {
+        MultiTensorArgs a = {};
+        a.count = count - lo < MT_MAX ? count - lo : MT_MAX;
+        for (int k = 0; k < a.count; ++k) {
+            RAFT_REQUIRE_PTR(xs[lo + k]);
+            RAFT_REQUIRE(ns[lo + k] > 0, RAFT_E_SHAPE);
+            a.p[k] = const_cast<float *>(xs[lo + k]);
+            a.n[k] = ns[lo + k];
+        }
+        sumsq_multi_partial_kernel<<<dim3(MT_BLOCKS, a.count), 256, 0, s>>>(a, workspace + (int64_t)lo * MT_BLOCKS);
+        RAFT_TRY(raft_launch_status());
+    }
+    sumsq_final_kernel<<<1, 64, 0, s>>>(workspace, count * MT_BLOCKS, 0, out);
+    return raft_launch_status();
+}
+
+// raft_adamw_step_f32 over `count` tensors per launch (chunks of 64): the same arithmetic per element.
+extern "C" int raft_adamw_step_multi_f32(float *const *vars, const float *const *grads, float *const *ms, float *const *vs,
+                                         const int64_t *ns, int count, float lr_t, float beta1, float beta2, float epsilon,
+                                         float weight_decay, const double *global_norm_sq, float clip_norm, void *stream) {
+    RAFT_REQUIRE_PTR(vars); RAFT_REQUIRE_PTR(grads); RAFT_REQUIRE_PTR(ms); RAFT_REQUIRE_PTR(vs); RAFT_REQUIRE_PTR(ns);
+    RAFT_REQUIRE(count > 0, RAFT_E_SHAPE);
+    hipStream_t s = (hipStream_t)stream;
+    for (int lo = 0; lo < count; lo += MT_MAX) {
+        MultiTensorArgs a = {};
+        a.count = count - lo < MT_MAX ? count - lo : MT_MAX;
+        int64_t nmax = 0;
+        for (int k = 0; k < a.count; ++k) {
+            RAFT_REQUIRE_PTR(vars[lo + k]); RAFT_REQUIRE_PTR(grads[lo + k]); RAFT_REQUIRE_PTR(ms[lo + k]); RAFT_REQUIRE_PTR(vs[lo + k]);
+            RAFT_REQUIRE(ns[lo + k] > 0, RAFT_E_SHAPE);
+            a.p[k] = vars[lo + k]; a.g[k] = grads[lo + k]; a.m[k] = ms[lo + k]; a.v[k] = vs[lo + k]; a.n[k] = ns[lo + k];
+            if (ns[lo + k] > nmax) nmax = ns[lo + k];
+        }
+        int gx = (int)raft_ceil_div(nmax, 256 * 8);   // ~8 elements per thread of the largest tensor; small tensors finish early
+        if (gx < 1) gx = 1;
+        if (gx > 256) gx = 256;
+        adamw_multi_kernel<<<dim3(gx, a.count), 256, 0, s>>>(a, lr_t, beta1, beta2, epsilon, weight_decay, global_norm_sq, clip_norm);
+        RAFT_TRY(raft_launch_status());
+    }
+    return RAFT_OK;
+}
 
 extern "C" int raft_sumsq_f32(const float *x, int64_t n, int accumulate, double *out, double *workspace, void *stream) {
     RAFT_REQUIRE_PTR(x); RAFT_REQUIRE_PTR(out); RAFT_REQUIRE_PTR(workspace);

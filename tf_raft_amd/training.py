@@ -6,6 +6,7 @@ out of scope.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import torch
@@ -62,35 +63,45 @@ class AdamW:
         return float(lr(self.iterations)) if callable(lr) else float(lr)
 
     def global_norm_sq(self, grads):
-        """Squared global norm of ``grads`` (dict or list of device tensors) as a float64 device scalar."""
+        """Squared global norm of ``grads`` (dict or list of device tensors) as a float64 device scalar: one multi-tensor
+        launch per 64 tensors + one ordered final sum (``raft_sumsq_multi_f32``)."""
         lib = _dev.lib()
-        tensors = list(grads.values()) if isinstance(grads, dict) else list(grads)
+        tensors = [g.as_subclass(torch.Tensor).contiguous() for g in (grads.values() if isinstance(grads, dict) else grads)]
         dev = tensors[0].device
-        if self._norm is None or self._norm[0].device != dev:
-            self._norm = (torch.zeros((1,), dtype=torch.float64, device=dev),
-                          torch.empty((int(lib.raft_sumsq_workspace_doubles()),), dtype=torch.float64, device=dev))
+        n = len(tensors)
+        need = int(lib.raft_sumsq_multi_workspace_doubles(n))
+        if self._norm is None or self._norm[0].device != dev or self._norm[1].numel() < need:
+            self._norm = (torch.zeros((1,), dtype=torch.float64, device=dev), torch.empty((need,), dtype=torch.float64, device=dev))
         out, ws = self._norm
-        for k, g in enumerate(tensors):
-            g = g.as_subclass(torch.Tensor).contiguous()
-            check(lib.raft_sumsq_f32(_dev.ptr(g), g.numel(), 1 if k else 0, _dev.ptr(out), _dev.ptr(ws), _dev.stream_ptr()), 'sumsq')
+        ptrs = (C.c_void_p * n)(*[_dev.ptr(g) for g in tensors])
+        sizes = (C.c_int64 * n)(*[g.numel() for g in tensors])
+        check(lib.raft_sumsq_multi_f32(ptrs, sizes, n, _dev.ptr(out), _dev.ptr(ws), _dev.stream_ptr()), 'sumsq_multi')
         return out
 
     def apply_gradients(self, grads, variables, clip_norm=None):
         """``variables`` / ``grads``: dicts name -> fp32 device tensor (variables are updated in place).  ``clip_norm``:
-        ``tf.clip_by_global_norm`` (reference model.py:134) folded into the update kernel."""
+        ``tf.clip_by_global_norm`` (reference model.py:134) folded into the update kernel.  All tensors go through
+        ``raft_adamw_step_multi_f32``: one launch per 64 tensors."""
         lib = _dev.lib()
         t = self.iterations + 1
         lr = self._lr()
         wd = float(self.weight_decay(self.iterations)) if callable(self.weight_decay) else float(self.weight_decay)
         lr_t = lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
         gn = self.global_norm_sq({k: grads[k] for k in variables}) if clip_norm is not None else None
-        for name, var in variables.items():
-            g = grads[name].as_subclass(torch.Tensor).contiguous()
+        names = list(variables)
+        if not names:
+            self.iterations += 1
+            return gn
+        gs = [grads[k].as_subclass(torch.Tensor).contiguous() for k in names]
+        for name in names:
             if name not in self._slots:
-                self._slots[name] = (torch.zeros_like(var), torch.zeros_like(var))
-            m, v = self._slots[name]
-            check(lib.raft_adamw_step_f32(_dev.ptr(var), _dev.ptr(g), _dev.ptr(m), _dev.ptr(v), var.numel(), lr_t, self.beta_1,
-                                          self.beta_2, self.epsilon, wd, _dev.ptr(gn) if gn is not None else None,
-                                          float(clip_norm) if clip_norm is not None else 0.0, _dev.stream_ptr()), 'adamw_step')
+                self._slots[name] = (torch.zeros_like(variables[name]), torch.zeros_like(variables[name]))
+        n = len(names)
+        arr = lambda ts: (C.c_void_p * n)(*[_dev.ptr(x) for x in ts])      # noqa: E731
+        sizes = (C.c_int64 * n)(*[variables[k].numel() for k in names])
+        check(lib.raft_adamw_step_multi_f32(arr([variables[k] for k in names]), arr(gs), arr([self._slots[k][0] for k in names]),
+                                            arr([self._slots[k][1] for k in names]), sizes, n, lr_t, self.beta_1, self.beta_2,
+                                            self.epsilon, wd, _dev.ptr(gn) if gn is not None else None,
+                                            float(clip_norm) if clip_norm is not None else 0.0, _dev.stream_ptr()), 'adamw_step_multi')
         self.iterations += 1
         return gn
