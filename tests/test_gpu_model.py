@@ -593,6 +593,7 @@ def test_rotating_buffer_loop_is_bitwise_the_single_stream_loop(shape, iters, ra
     import tf_raft_amd
     B, H, W = shape
     i1, i2, wts = _conditioned_case('raft', H, W, 2, B=B)
+    raft_opt.set('RAFT_MASK_FUSED', '1')          # the schedule belongs to the fused mask kernel (default only from 4 pairs on)
     ref = [_np(p) for p in tf_raft_amd.RAFT(weights=wts, iters_pred=iters, overlap=False)([i1, i2])]
     for opt in ('1', '0'):
         raft_opt.set('RAFT_LOOP_ROTATE', opt)

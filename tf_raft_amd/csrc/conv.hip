@@ -12,9 +12,12 @@
 // mask.2 + RAFT.upsample_flow in one kernel (mask_upsample.hip)
 int raft_launch_mask_upsample(const float *a, int lda, const float *wp, const float *bias, int npad, const float *flow, int B,
                               int h, int w, float scale, float *out, hipStream_t s);
-// RAFT_MASK_FUSED (default 1): the prediction loops run mask.2 and the convex upsampling as one kernel
-static bool mask_is_fused(const raft_basic_update_weights *wts) {
-    return raft_opt(RAFT_OPT_MASK_FUSED, 1) != 0 && wts->mask2.wp != nullptr && wts->mask2.npad == 576;
+// RAFT_MASK_FUSED: the prediction loops run mask.2 and the convex upsampling as one kernel.  Default: from 4 pairs (4 x 3584
+// feature pixels) on -- its 64-pixel workgroups are 56 per pair, and below that the two-kernel path's shorter workgroups
+// finish sooner (one process, profiles/r08k_round3_options.txt: single pair 152.7 pairs/s with two kernels, 137.8 - 142.0 fused;
+// two pairs 210.7 / 205.4; four 282.7 / 288.4, eight 313.0 / 317.7 in r07q)
+static bool mask_is_fused(const raft_basic_update_weights *wts, int64_t pixels) {
+    return raft_opt(RAFT_OPT_MASK_FUSED, pixels >= 4 * 3584 ? 1 : 0) != 0 && wts->mask2.wp != nullptr && wts->mask2.npad == 576;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -272,12 +275,13 @@ constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr,
 // F(4x4, 3x3) (conv_wino4.h), switch RAFT_CONV_WINO4 = bit mask {1: convc2, 4: conv, 8: fh1_mask0 / fh1}.  Default (us alone,
 // F(4x4) against F(2x2), profiles/r07i_wino4_bench.txt): from 4 pairs on the flow / mask head (63 vs 91 at 4 pairs, 128 vs 169 at
 // 8) and convc2 (61 vs 76 with the K-split workgroups, 107 vs 132); conv (N = 128) from 8 pairs on (65 vs 114; at 4 pairs its
-// 112 K-split workgroups lose to F(2x2): 59 vs 49).  Below 4 pairs nothing: a launch is then one round of workgroups whose
+// 112 K-split workgroups lose to F(2x2): 59 vs 49).  A single pair nothing: a launch is then one round of workgroups whose
 // duration is one workgroup's K loop, and the one-wave-per-SIMD F(4x4) workgroup is the longer one (single pair: 151 pairs/s
-// without, 133 with -- same-box A/B with bench.py, profiles/r07p_bench_mask_ab.txt: 4 pairs 270 -> 282, 8 pairs 285 -> 296).
+// without, 133 with -- same-box A/B with bench.py, profiles/r07p_bench_mask_ab.txt: 4 pairs 270 -> 282, 8 pairs 285 -> 296);
+// two pairs DO gain (205 -> 235 pairs/s with mask 9, 219 with 13: profiles/r08k_round3_options.txt).
 static int wino4_default_mask(const ConvArgs &a) {
     const int64_t m = (int64_t)a.B * a.H * a.W;
-    return m < 4 * 3584 ? 0 : (8 | 1 | (m >= 8 * 3584 ? 4 : 0));
+    return m < 2 * 3584 ? 0 : (8 | 1 | (m >= 8 * 3584 ? 4 : 0));
 }
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
                           hipStream_t s, bool small = false, const raft_conv_weights *wino44 = nullptr) {
@@ -771,7 +775,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         RAFT_TRY(launch_conv3x3(wts->fh1_mask0, wts->fh1_mask0_w, 8, a, EPI_RELU, s, false, &wts->fh1_mask0_w44));
         RAFT_MARK();
     } else {           // relu(flow_head.conv1(net)) only            3x3, 128 -> 256        -> fm[:, 0:256]
-        const bool w44 = wts->fh1_w44.wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, (int64_t)B * h * w < 4 * 3584 ? 0 : 8) & 8);
+        const bool w44 = wts->fh1_w44.wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, (int64_t)B * h * w < 2 * 3584 ? 0 : 8) & 8);
         ConvArgs a = conv_args(w44 ? wts->fh1_w44 : wts->fh1_w, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 256, fm, 512);
         RAFT_TRY(w44 ? raft_launch_conv_wino4(a, EPI_RELU, s, wts->fh1_mask0_w44.npad) : raft_launch_conv_wino(a, EPI_RELU, s));
     }
@@ -821,7 +825,7 @@ extern "C" int raft_iterate_basic_f32(const raft_basic_update_weights *wts, cons
     const bool fused = lookup_is_fused(wts, &src);
     for (int i = 0; i < iters; ++i) {
         if (!fused) RAFT_TRY(raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream));
-        const bool mf = mask_is_fused(wts);
+        const bool mf = mask_is_fused(wts, (int64_t)B * h * w);
         RAFT_TRY(update_basic_impl(wts, B, h, w, st, stream, nullptr, nullptr, true, fused ? &src : nullptr, mf ? flow_up + i * up : nullptr));
         if (!mf) RAFT_TRY(raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream));
     }
@@ -940,7 +944,7 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
     ov.e_up = ctx->ev[3];
     ov.e_rot[0] = ctx->ev[2];   // e_fm is not used in that mode
     ov.e_rot[1] = ctx->ev[3];
-    ov.rot = !final_only && mask_is_fused(wts) && raft_opt(RAFT_OPT_LOOP_ROTATE, 1) != 0;
+    ov.rot = !final_only && mask_is_fused(wts, (int64_t)B * h * w) && raft_opt(RAFT_OPT_LOOP_ROTATE, 1) != 0;
     const int64_t up = (int64_t)B * 64 * h * w * 2;
     int rc = (int)hipEventRecord(ov.e_fh, s);   // state prepared on `stream`: the flow branch may start
     for (int i = 0; i < iters && rc == RAFT_OK; ++i) {
@@ -948,7 +952,7 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
         const bool fused = lookup_is_fused(wts, &src);
         rc = fused ? RAFT_OK : loop_lookup(src, st, B, h, w, stream);
         float *up_i = flow_up + (final_only ? 0 : i * up);
-        const bool mf = with_mask && mask_is_fused(wts);
+        const bool mf = with_mask && mask_is_fused(wts, (int64_t)B * h * w);
         ov.iter = i;
         if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov, with_mask, fused ? &src : nullptr, mf ? up_i : nullptr);
         if (!with_mask) continue;
@@ -1087,7 +1091,7 @@ extern "C" int raft_iterate_basic_timed_f32(const raft_basic_update_weights *wts
         if (!fused) rc = raft_corr_lookup_f32(pyr, level_offsets, st->coords1, B, h, w, 4, 4, st->corr, CORR_LD, stream);
         tm.mark(s);
         // RAFT_MASK_FUSED likewise: fused, the mask2 stage is the fused kernel and the upsampling stage is empty
-        const bool mf = mask_is_fused(wts);
+        const bool mf = mask_is_fused(wts, (int64_t)B * h * w);
         if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, &tm, nullptr, true, fused ? &src : nullptr, mf ? flow_up + i * up : nullptr);
         if (rc == RAFT_OK && !mf) rc = raft_upsample_convex_f32(st->flow, st->mask, B, h, w, flow_up + i * up, stream);
         tm.mark(s);
