@@ -231,12 +231,14 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
         if (tiles_w > tiles_max) tiles_max = tiles_w;
     }
     const bool use_wino = raft_opt(RAFT_OPT_ENC_WINO, 1) != 0;   // 0: direct 3x3 kernels everywhere (A/B timing, parity tests)
-    // stages whose stride-1 3x3 layers run the F(4x4, 3x3) kernel (bit 0 = layer1 ...).  Default: every stage whose launch has
-    // at least 100 of the kernel's 8 x 64-pixel x 64-channel workgroups -- at 4 pairs everything but cnet's layer3 (56).  Per
-    // kernel at 4 pairs (profiles/r07u_encoder_kernels_b4.txt): fnet's ten layers 1308 -> 1120 us, the 64-channel half-resolution
-    // layers ~190 -> ~150 us each (K = 64 is only four 16-channel chunks: prologue and output transform are 40 % of a workgroup);
-    // a layer3 launch with the K-split variant is slower than F(2x2) (41 against 28 us).  An explicit RAFT_ENC_WINO4 is
-    // taken as given.
+    // stages whose stride-1 3x3 layers run the F(4x4, 3x3) kernel (bit 0 = layer1 ...).  Default: every layer whose launch is
+    // MORE than one round of the kernel's 8 x 64-pixel x 64-channel workgroups on the chip (> 256) -- at 4 pairs fnet's layer1 / layer2
+    // (896 / 448) and cnet's layer1 (448).  Per kernel at 4 pairs (profiles/r07u_encoder_kernels_b4.txt): fnet's ten layers
+    // 1308 -> 1120 us, the 64-channel half-resolution layers ~190 -> ~150 us each (K = 64 is only four 16-channel chunks:
+    // prologue and output transform are 40 % of a workgroup); a layer3 launch with the K-split variant is slower than F(2x2)
+    // (41 against 28 us).  Launches of a single round gain nothing measurable (one / two pairs: 137.2 / 203.8 pairs/s without,
+    // 137.2 / 204.5 with every stage on it, profiles/r08k_round3_options.txt) and F(4x4) is the noisier algorithm (3.3e-6 against
+    // 1.9e-6 of the output scale), so they stay on F(2x2).  An explicit RAFT_ENC_WINO4 is taken as given.
     const int wino4_mask = use_wino ? raft_opt(RAFT_OPT_ENC_WINO4, 7) : 0;
     const bool wino4_forced = raft_opt_is_set(RAFT_OPT_ENC_WINO4);
     EncBufs b;
@@ -329,7 +331,7 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
         const EncKind k1 = stride == 2 ? ENC_3x3_S2 : ENC_3x3_S1;
         const int ni = 1 + blk * 3;   // index of this block's norm1 in in_gamma / in_beta
         const bool w4 = ((wino4_mask >> (blk / 2)) & 1) &&
-                        (wino4_forced || (int64_t)n * ((Ho + 7) / 8) * ((Wo + 63) / 64) * ((F + 63) / 64) >= 100);
+                        (wino4_forced || (int64_t)n * ((Ho + 7) / 8) * ((Wo + 63) / 64) * ((F + 63) / 64) > 256);
         const raft_conv_weights *w44a = w4 ? &w->block_w44[blk][0] : nullptr, *w44b = w4 ? &w->block_w44[blk][1] : nullptr;
         if (inorm) {
             RAFT_TRY(conv(k1, c1, x, C, Hc, Wc, Ho, Wo, p1t, p1l, F, EPI_LINEAR, b.r1, nullptr, nullptr, nullptr, 0,
