@@ -20,12 +20,18 @@
 //     2 G floats -- conflict-free (tools/bank_check.py wino4).  A chunk is processed as two halves h (k-steps 2h, 2h + 1 of
 //     every tap) so that the transform works on 2 channels per lane: W and V are 12 registers a row instead of 24.
 //   * A half is three PHASES of two tap rows each -- (+a, -a), (+b, -b), (0, inf): rows of a pair share their even / odd
-//     parts.  Stage 1 (B^T over the patch rows -> W[2][6]) of phase k + 1 is spread over the 12 tap slots of phase k (LDS
-//     reads in even slots, arithmetic in odd slots); stage 2 (W -> V, one tap ahead) and the weight fragments (PF slots
-//     ahead, straight from L2 as b64 per lane and column block) ride in the same slots; a slot ends in its 4 MFMAs
-//     (2 k-steps x 2 column blocks).  The next chunk's halo tile is fetched item by item in slots 4..14 and written to the
-//     other LDS buffer in slots 10..20; the chunk's barrier sits in front of its last phase, whose stage-1 reads already
-//     belong to the next chunk.
+//     parts -- and a phase is 12 tap SLOTS of four MFMAs (2 k-steps x 2 column blocks): 72 slots per chunk.  Patch rows 1..4 of
+//     a half are read ONCE into 48 registers (every phase needs them: under the last phase of the previous half), rows 0 / 5
+//     when the (0, inf) rows are formed -- 72 ds_read_b64 per chunk.  Stage 1 (B^T over the patch rows -> W[2][2][6]) of phase
+//     k + 1 is spread over the slots of phase k (LDS reads in even slots, arithmetic in odd slots); stage 2 (W -> V) runs one
+//     tap ahead; the weight fragments arrive RAFT_WINO4_PF (7) slots ahead, straight from L2: the stream is packed in
+//     consumption order, so a slot's fragments for both column blocks are one 16-byte load at ONE running scalar offset.
+//     The next chunk's halo tile is fetched item by item in slots 0..NA-1 (scalar channel offset: no address arithmetic) and
+//     written to the other LDS buffer RAFT_WINO4_LAG (12) slots later; the chunk's barrier sits in front of its last phase,
+//     whose stage-1 reads already belong to the next chunk.  Two chunks per loop trip (one per LDS buffer: every LDS access is
+//     base register + immediate); an odd chunk count runs one ghost chunk on zeros.
+//   * 72 accumulator tiles are 288 registers: MFMAs are inline asm, taps 0..30 accumulate in AGPRs, 31..35 in VGPRs (hipcc
+//     picks one register class for all builtin MFMAs of a function and shuffles the overflow through copies otherwise).
 //   * epilogue: A^T . A over the 36 accumulators of a column block (lane-local), bias, relu / residual, stores with one lane
 //     base per tensor + wave-uniform element offsets (as conv_wino.h).
 #pragma once

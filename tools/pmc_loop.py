@@ -1,6 +1,6 @@
 """Workload of the PMC passes (tools/pmc_traffic.sh): ONE full forward (encoders, volume build, state preparation) and
 then the SINGLE-STREAM prediction loop, `iters` iterations, at batch B -- first with the product default (lookup fused into
-convc1: that kernel is attributed by name), then with RAFT_LOOKUP_FUSED=0, where the launch order inside an iteration is
+convc1, mask.2 into the upsampling: those kernels are attributed by name), then with RAFT_LOOKUP_FUSED=0 RAFT_MASK_FUSED=0, where the launch order inside an iteration is
 fixed (bench.py STAGES), which is how tools/pmc_traffic.py attributes those dispatches to stages.
 usage: python tools/pmc_loop.py <batch> <iters>"""
 import os
@@ -22,7 +22,8 @@ from tf_raft_amd import _ffi  # noqa: E402
 model = tf_raft_amd.RAFT(iters_pred=iters, overlap=False)
 out = model([i1, i2])                            # product default: lookup fused into convc1 (attributed by kernel name)
 torch.cuda.synchronize()
-_ffi.set_option('RAFT_LOOKUP_FUSED', 0)          # then the two-kernel loop: 14 kernels per iteration, attributed by order
+_ffi.set_option('RAFT_LOOKUP_FUSED', 0)          # then the two-kernel loops: 14 kernels per iteration, attributed by order
+_ffi.set_option('RAFT_MASK_FUSED', 0)            # (mask.2 and the upsampling as their own kernels too)
 out = model([i1, i2])
 torch.cuda.synchronize()
 print('done', float(out[-1].abs().max()))
