@@ -278,10 +278,11 @@ constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr,
 // 112 K-split workgroups lose to F(2x2): 59 vs 49).  A single pair nothing: a launch is then one round of workgroups whose
 // duration is one workgroup's K loop, and the one-wave-per-SIMD F(4x4) workgroup is the longer one (single pair: 151 pairs/s
 // without, 133 with -- same-box A/B with bench.py, profiles/r07p_bench_mask_ab.txt: 4 pairs 270 -> 282, 8 pairs 285 -> 296);
-// two pairs DO gain (205 -> 235 pairs/s with mask 9, 219 with 13: profiles/r08k_round3_options.txt).
+// at two pairs the flow / mask head alone gains (206 -> 221 pairs/s with mask 8 on two boxes; with convc2 as well 214 and one
+// outlier of 235: profiles/r08k_round3_options.txt, r08z_b2_options.txt).
 static int wino4_default_mask(const ConvArgs &a) {
     const int64_t m = (int64_t)a.B * a.H * a.W;
-    return m < 2 * 3584 ? 0 : (8 | 1 | (m >= 8 * 3584 ? 4 : 0));
+    return m < 2 * 3584 ? 0 : (8 | (m >= 4 * 3584 ? 1 : 0) | (m >= 8 * 3584 ? 4 : 0));
 }
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
                           hipStream_t s, bool small = false, const raft_conv_weights *wino44 = nullptr) {
