@@ -285,14 +285,14 @@ static int wino4_default_mask(const ConvArgs &a) {
     return m < 2 * 3584 ? 0 : (8 | (m >= 4 * 3584 ? 1 : 0) | (m >= 8 * 3584 ? 4 : 0));
 }
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
-                          hipStream_t s, bool small = false, const raft_conv_weights *wino44 = nullptr) {
+                          hipStream_t s, bool small = false, const raft_conv_weights *wino44 = nullptr, int w4_ks_hint = 0) {
     const int mask = small ? raft_opt(RAFT_OPT_SMALL_WINO, RAFT_SMALL_WINO_DEFAULT) : raft_opt(RAFT_OPT_CONV_WINO, RAFT_WINO_DEFAULT);
     if (wino44 != nullptr && wino44->wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, wino4_default_mask(a)) & bit) &&
         (epi == EPI_LINEAR || epi == EPI_RELU || epi == EPI_RES)) {
         a.wp = wino44->wp;
         a.bias = wino44->bias;
         a.npad = wino44->npad;
-        return raft_launch_conv_wino4(a, epi, s);
+        return raft_launch_conv_wino4(a, epi, s, 0, w4_ks_hint);
     }
     if ((mask & bit) && wino.wp != nullptr) {
         a.wp = wino.wp;
@@ -720,7 +720,12 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     {   // cor = relu(convc2(cor))             3x3, 256 -> 192   -> corflo[:, 0:192]
         ConvArgs a = conv_args(wts->convc2, cor1, 256, 256, nullptr, 0, 0, B, h, w, 192, corflo, 256);
-        RAFT_TRY(launch_conv3x3(wts->convc2, wts->convc2_w, 1, a, EPI_RELU, s, false, &wts->convc2_w44));
+        // F(4x4): 8-row workgroups without the K split even where they are fewer than half the CUs (84 at 4 pairs).  Alone the
+        // K-split launch is faster (61 against 99 us), but it occupies 168 CUs for 61 us where this one takes 84 for 99: 18 % less
+        // CU-time, and in the loop the flow branch and the mask branch run on the CUs it leaves free -- same box, one process
+        // (profiles/r08n_b4_options.txt): 288.7 -> 293.7 pairs/s at 4 pairs.  Every loop uses the same shape (the loops stay
+        // bit-identical to each other); flow_head.conv1 of the final-only loop keeps the grid rule (316 against 309 pairs/s).
+        RAFT_TRY(launch_conv3x3(wts->convc2, wts->convc2_w, 1, a, EPI_RELU, s, false, &wts->convc2_w44, 1));
         RAFT_MARK();
     }
     if (ov) RAFT_HIP(hipStreamWaitEvent(sf, ov->e_fh, 0));   // flow of the previous iteration is final

@@ -599,4 +599,6 @@ __global__ void __launch_bounds__(256, 1) conv_wino4_kernel(ConvArgs p) {
 // (Cin/16, 72, 4, npad/32, 16, 2, 2) -- tf_raft_amd/packing.py pack_conv_winograd4.  epi: EPI_LINEAR / EPI_RELU / EPI_RES;
 // a.stats != NULL (with EPI_LINEAR) selects STATS, a.pre_scale != NULL PRE on top of it (the instance-norm encoder's
 // combinations; one source, two-row-block workgroups).  Stats entries per image: 2 * ceil(H/8) * ceil(W/64).
-int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide_npad = 0);
+// ks_hint = 1 / 2: the caller's choice of the workgroup shape where the launcher would decide by grid size (an explicit
+// RAFT_WINO4_KS still wins).
+int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide_npad = 0, int ks_hint = 0);

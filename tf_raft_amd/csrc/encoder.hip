@@ -17,7 +17,7 @@
 #include "conv_wino.h"
 
 // F(4x4, 3x3) launcher (conv_wino4.hip; the kernel header is not needed here)
-int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide_npad = 0);
+int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide_npad = 0, int ks_hint = 0);
 
 namespace {
 
