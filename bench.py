@@ -536,6 +536,16 @@ def main():
                 roof['direct_conv_flops_per_launch'] = flops[dom]
                 roof['algorithmic_tflops'] = round(alg, 2)    # direct-convolution FLOPs / time: may exceed the peak
                 roof['frac_algorithmic'] = round(alg / PEAK_FP32_MFMA_TFLOPS, 4)
+            if ratio == 4.0 and dom == 'convc2':
+                # convc2 on F(4x4) runs 8 x 64-pixel x 64-channel workgroups WITHOUT the K split (csrc/conv.hip): fewer than the
+                # chip has CUs at small batches, by choice -- the launch takes 18 % less CU-time than the K-split one and the
+                # flow / mask branches of the three-stream loop run on the CUs it leaves free (same-box A/B in DESIGN 4.5).  The
+                # whole-chip fraction above is therefore low by construction; the fraction on the CUs it occupies is beside it
+                wgs = B * ((h + 7) // 8) * ((w + 63) // 64) * 3
+                occ = min(1.0, wgs / 256.0)
+                roof['launch'] = {'workgroups': wgs, 'cus': 256, 'occupied_cu_frac': round(occ, 4),
+                                  'frac_on_occupied_cus': round(ach / PEAK_FP32_MFMA_TFLOPS / occ, 4),
+                                  'note': 'one workgroup per CU; the side branches of the three-stream loop use the other CUs'}
         else:
             ach = bytes_[dom] / (stage_ms[dom] * 1e-3) / 1e9
             tr, note = pmc_traffic(dom, B)
