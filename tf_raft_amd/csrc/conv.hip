@@ -11,7 +11,7 @@
 
 // mask.2 + RAFT.upsample_flow in one kernel (mask_upsample.hip)
 int raft_launch_mask_upsample(const float *a, int lda, const float *wp, const float *bias, int npad, const float *flow, int B,
-                              int h, int w, float scale, float *out, hipStream_t s);
+                              int h, int w, float scale, float *out, hipStream_t s, int max_wgs = 0);
 // RAFT_MASK_FUSED: the prediction loops run mask.2 and the convex upsampling as one kernel.  Default: from 4 pairs (4 x 3584
 // feature pixels) on -- its 64-pixel workgroups are 56 per pair, and below that the two-kernel path's shorter workgroups
 // finish sooner (one process, profiles/r08k_round3_options.txt: single pair 152.7 pairs/s with two kernels, 137.8 - 142.0 fused;
@@ -676,6 +676,11 @@ struct Overlap {
     bool rot;
     int iter;
     hipEvent_t e_rot[2];
+    // Background mask branch (rot only): every iteration but the last launches the mask + upsampling kernel with at most this
+    // many workgroups (0 = one per tile).  The chain's kernels have 7 * 2^k workgroups at 448 x 512 and leave 32 CUs idle; 32
+    // long-lived mask workgroups settle there (their 95 KB of LDS keep chain workgroups off those CUs) instead of competing
+    // with the chain for all of them.  The last iteration's launch is a full one: nothing is left to hide behind.
+    int mask_bg_wgs;
 };
 #define RAFT_HIP(expr)                       \
     do {                                     \
@@ -801,7 +806,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         // branch already waits for fh1_mask0) it needs the flow fh2 has just written.
         if (ov) RAFT_HIP(hipStreamWaitEvent(sm, ov->e_fh, 0));
         RAFT_TRY(raft_launch_mask_upsample(fm + 256, 512, wts->mask2.wp, wts->mask2.bias, wts->mask2.npad, rot ? flowm : st->flow, B, h, w,
-                                           0.25f, flow_up_fused, sm));
+                                           0.25f, flow_up_fused, sm, rot ? ov->mask_bg_wgs : 0));
         RAFT_MARK();
     } else if (with_mask) {   // mask = 0.25 * mask.2(.)             1x1, 256 -> 576
         ConvArgs a = conv_args(wts->mask2, fm + 256, 512, 256, nullptr, 0, 0, B, h, w, 576, st->mask, 576);
@@ -960,6 +965,7 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
         float *up_i = flow_up + (final_only ? 0 : i * up);
         const bool mf = with_mask && mask_is_fused(wts, (int64_t)B * h * w);
         ov.iter = i;
+        ov.mask_bg_wgs = (ov.rot && i + 1 < iters) ? raft_opt(RAFT_OPT_MASK_BG_WGS, 32) : 0;
         if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov, with_mask, fused ? &src : nullptr, mf ? up_i : nullptr);
         if (!with_mask) continue;
         if (!mf) {

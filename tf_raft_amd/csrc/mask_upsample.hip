@@ -38,9 +38,13 @@ __global__ void __launch_bounds__(512) mask_upsample_kernel(MaskUpArgs p) {
     const int G = lane >> 4, LR = lane & 15;
     const int rbp = wv & 1, cg = wv >> 1;                                // tile rows {2 rbp, 2 rbp + 1}; column blocks 9 cg .. 9 cg + 8
     const int tiles_x = (p.w + MU_TW - 1) / MU_TW, tiles_y = (p.h + MU_TH - 1) / MU_TH;
-    int bid = blockIdx.x;   // XCD-aware remap (see conv_halo.h)
+    const int ntiles = p.B * tiles_x * tiles_y;
+    // A launch may have FEWER workgroups than tiles (background mode, see raft_launch_mask_upsample): workgroup g walks the tiles
+    // g, g + gridDim.x, ...
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;   // XCD-aware remap (see conv_halo.h)
     {
-        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int nwg = ntiles, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = bid / (tiles_x * tiles_y);
@@ -175,20 +179,26 @@ __global__ void __launch_bounds__(512) mask_upsample_kernel(MaskUpArgs p) {
             *o = make_float2(ox, oy);
         }
     }
+    raft_barrier_lds();   // the next tile's staging rewrites sa / sf, its epilogue sm
+  }
 }
 }   // namespace
 
 // mask = 0.25 * mask.2(a) (1x1, 256 -> 576) and flow_up = RAFT.upsample_flow(flow, mask) in one kernel; `a` = (B*h*w, lda) with
 // the 256 input channels first, `wp` / `bias` = mask.2 packed for the direct kernels (npad 576).  Internal (conv.hip loops).
+// max_wgs > 0: BACKGROUND mode -- at most that many workgroups, each walking several tiles.  At 448 x 512 every kernel of the
+// dependent chain has 7 * 2^k workgroups (56 feature rows), i.e. it leaves 32 of the 256 CUs idle; a mask branch of 32 long-lived
+// workgroups (95 KB of LDS each: no chain workgroup fits beside one) settles on 32 CUs and the chain takes the other 224.
 int raft_launch_mask_upsample(const float *a, int lda, const float *wp, const float *bias, int npad, const float *flow, int B,
-                              int h, int w, float scale, float *out, hipStream_t s) {
+                              int h, int w, float scale, float *out, hipStream_t s, int max_wgs) {
     if (a == nullptr || wp == nullptr || bias == nullptr || flow == nullptr || out == nullptr) return RAFT_E_NULL;
     if (B <= 0 || h <= 0 || w <= 0) return RAFT_E_SHAPE;
     if (npad != MU_N || lda < MU_K || lda % 4) return RAFT_E_UNSUPPORTED;
     if (!raft_aligned16(a) || !raft_aligned16(wp)) return RAFT_E_ALIGN;
     if ((int64_t)B * h * w * lda * 4 >= ((int64_t)1 << 31)) return RAFT_E_UNSUPPORTED;
     MaskUpArgs p = {a, lda, wp, bias, flow, out, B, h, w, scale};
-    const int grid = B * ((h + MU_TH - 1) / MU_TH) * ((w + MU_TW - 1) / MU_TW);
+    int grid = B * ((h + MU_TH - 1) / MU_TH) * ((w + MU_TW - 1) / MU_TW);
+    if (max_wgs > 0 && grid > max_wgs) grid = max_wgs;
     mask_upsample_kernel<<<grid, 512, 0, s>>>(p);
     return raft_launch_status();
 }
