@@ -50,7 +50,7 @@
  *   RAFT_LOOP_ROTATE    0/1  three-stream all-predictions loop with the fused mask kernel: two event operations per iteration on
  *                            the main stream instead of four ([fh1 | mask.0] and the mask branch's flow alternate between two buffers) (default 1)
  *   RAFT_MASK_BG_WGS    workgroups of the mask + upsampling kernel in the three-stream loop's iterations 0 .. n-2 (each walks
- *                       several tiles; 0 = one workgroup per tile)                              (default 32)
+ *                       several tiles; 0 = one workgroup per tile)     (default 32; 0 where the chain's launches fill all CUs exactly)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)

@@ -965,7 +965,11 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
         float *up_i = flow_up + (final_only ? 0 : i * up);
         const bool mf = with_mask && mask_is_fused(wts, (int64_t)B * h * w);
         ov.iter = i;
-        ov.mask_bg_wgs = (ov.rot && i + 1 < iters) ? raft_opt(RAFT_OPT_MASK_BG_WGS, 32) : 0;
+        // default 32, except where the chain's launches cover the chip exactly (the flow / mask head's F(4x4) grid a multiple of
+        // 256: a single 1024 x 1024 pair loses 6 % to a background branch); one process, profiles/r09d_mask_bg_shapes.txt:
+        // 448 x 512 at 4 / 5 / 6 / 8 / 12 / 16 pairs +2.7 / +7.9 / +4.5 / +6.1 / +2.5 / +1.6 %, 16 or 40+ workgroups lose
+        const int head_grid = B * ((h + 7) / 8) * ((w + 63) / 64) * 8;
+        ov.mask_bg_wgs = (ov.rot && i + 1 < iters) ? raft_opt(RAFT_OPT_MASK_BG_WGS, head_grid % 256 ? 32 : 0) : 0;
         if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov, with_mask, fused ? &src : nullptr, mf ? up_i : nullptr);
         if (!with_mask) continue;
         if (!mf) {
