@@ -46,7 +46,7 @@
  *   RAFT_ENC_WINO4      bit mask {1 layer1, 2 layer2, 4 layer3}: stride-1 3x3 layers of those encoder stages on the
  *                       F(4x4,3x3) kernel where a transformed copy is present (block_w44)      (default: every layer whose launch has more than 256 workgroups)
  *   RAFT_LOOKUP_FUSED   0/1  prediction loops: lookup + convc1 as two kernels / fused (raft_lookup_convc1_f32)  (default 1)
- *   RAFT_MASK_FUSED     0/1  prediction loops: mask.2 + convex upsampling as two kernels / one (the mask is never stored) (default: 1 from 4 pairs at 448x512 on)
+ *   RAFT_MASK_FUSED     0/1  prediction loops: mask.2 + convex upsampling as two kernels / one (the mask is never stored) (default: 1 from 2 pairs at 448x512 on)
  *   RAFT_LOOP_ROTATE    0/1  three-stream all-predictions loop with the fused mask kernel: two event operations per iteration on
  *                            the main stream instead of four ([fh1 | mask.0] and the mask branch's flow alternate between two buffers) (default 1)
  *   RAFT_MASK_BG_WGS    workgroups of the mask + upsampling kernel in the three-stream loop's iterations 0 .. n-2 (each walks

@@ -12,12 +12,14 @@
 // mask.2 + RAFT.upsample_flow in one kernel (mask_upsample.hip)
 int raft_launch_mask_upsample(const float *a, int lda, const float *wp, const float *bias, int npad, const float *flow, int B,
                               int h, int w, float scale, float *out, hipStream_t s, int max_wgs = 0);
-// RAFT_MASK_FUSED: the prediction loops run mask.2 and the convex upsampling as one kernel.  Default: from 4 pairs (4 x 3584
-// feature pixels) on -- its 64-pixel workgroups are 56 per pair, and below that the two-kernel path's shorter workgroups
-// finish sooner (one process, profiles/r08k_round3_options.txt: single pair 152.7 pairs/s with two kernels, 137.8 - 142.0 fused;
-// two pairs 210.7 / 205.4; four 282.7 / 288.4, eight 313.0 / 317.7 in r07q)
+// RAFT_MASK_FUSED: the prediction loops run mask.2 and the convex upsampling as one kernel.  Default: from 2 pairs (2 x 3584
+// feature pixels) on.  Launched one workgroup per tile the fused kernel only pays from 4 pairs (single pair 152.7 pairs/s with two
+// kernels, 137.8 - 142.0 fused; two pairs 210.7 / 205.4; four 282.7 / 288.4: profiles/r08k_round3_options.txt, r07q); as the
+// 32-workgroup background branch of the three-stream loop (struct Overlap) it pays from 2 pairs: 225.5 -> 244.1 pairs/s at two,
+// 246.3 -> 256.3 at three (profiles/r09e_small_batch_mask.txt); a single pair stays on the two-kernel path (152 - 153 against
+// 148 - 155).
 static bool mask_is_fused(const raft_basic_update_weights *wts, int64_t pixels) {
-    return raft_opt(RAFT_OPT_MASK_FUSED, pixels >= 4 * 3584 ? 1 : 0) != 0 && wts->mask2.wp != nullptr && wts->mask2.npad == 576;
+    return raft_opt(RAFT_OPT_MASK_FUSED, pixels >= 2 * 3584 ? 1 : 0) != 0 && wts->mask2.wp != nullptr && wts->mask2.npad == 576;
 }
 
 // ------------------------------------------------------------------------------------------------
