@@ -19,6 +19,9 @@ for b in 4 8; do
   f=$(ls $out/${tag}_ss_b$b/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_single_stream_b${b}_rocprofv3_kernel_stats.csv
   rm -f $out/${tag}_ss_b$b/*kernel_trace.csv
 done
+timeout 200 rocprofv3 --kernel-trace -f csv -d $out/${tag}_tl -o tl -- python $root/tools/graph_probe.py 4 3 > $out/${tag}_tl.log 2>&1
+t=$(ls $out/${tag}_tl/*kernel_trace.csv 2>/dev/null | head -1)
+if [ -n "$t" ]; then python $root/tools/graph_trace.py $t "B=4 final" > $out/${tag}_loop_timeline_b4.txt 2>&1; python $root/tools/step_timeline.py $t all | awk 'NR>=72 && NR<=104' >> $out/${tag}_loop_timeline_b4.txt; rm -f $t; fi
 cd $root
 timeout 300 python tools/batch_sweep.py 8 2>&1 | grep "^B=" > $out/${tag}_batch_sweep.txt
 timeout 400 python tools/config_bench.py > $out/${tag}_config_bench.txt 2>&1
