@@ -51,6 +51,7 @@
  *                            the main stream instead of four ([fh1 | mask.0] and the mask branch's flow alternate between two buffers) (default 1)
  *   RAFT_MASK_BG_WGS    workgroups of the mask + upsampling kernel in the three-stream loop's iterations 0 .. n-2 (each walks
  *                       several tiles; 0 = one workgroup per tile)     (default 32; 0 where the chain's launches fill all CUs exactly)
+ *   RAFT_CONVC2_KS      1/2  convc2 on the F(4x4) kernel in the loops: 8-row workgroups / K-split 4-row workgroups   (default 1)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)
@@ -67,7 +68,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 214          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 215          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -269,6 +270,8 @@ typedef struct raft_basic_update_weights {
     /* optional: Winograd F(4x4, 3x3) transformed copies of convc2 / conv / fh1_mask0 and of flow_head.conv1 alone
      * (packing.py pack_conv_winograd4); preferred over the F(2x2, 3x3) copies where RAFT_CONV_WINO4 has the layer's bit */
     raft_conv_weights convc2_w44, conv_w44, fh1_mask0_w44, fh1_w44;
+    /* optional: the same for convf2 (RAFT_CONV_WINO4 bit 2) */
+    raft_conv_weights convf2_w44;
 } raft_basic_update_weights;
 
 /* Device state of the recurrent loop (all caller-owned, (B*h*w) pixels, NHWC):

@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 214     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 215     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -30,7 +30,7 @@ class BasicUpdateWeights(C.Structure):
         'convc2_w', 'convf2_w', 'conv_w', 'fh1_mask0_w',
         'gru_zr1_w', 'gru_q1_w', 'gru_zr2_w', 'gru_q2_w', 'fh1_w',
         'gru_zr1_w4', 'gru_q1_w4', 'gru_zr2_w4', 'gru_q2_w4', 'convc1_f', 'gru_ctx1_w4', 'gru_ctx2_w4',
-        'convc2_w44', 'conv_w44', 'fh1_mask0_w44', 'fh1_w44')]
+        'convc2_w44', 'conv_w44', 'fh1_mask0_w44', 'fh1_w44', 'convf2_w44')]
 
 
 class SmallUpdateWeights(C.Structure):

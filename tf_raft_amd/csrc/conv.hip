@@ -732,7 +732,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         // CU-time, and in the loop the flow branch and the mask branch run on the CUs it leaves free -- same box, one process
         // (profiles/r08n_b4_options.txt): 288.7 -> 293.7 pairs/s at 4 pairs.  Every loop uses the same shape (the loops stay
         // bit-identical to each other); flow_head.conv1 of the final-only loop keeps the grid rule (316 against 309 pairs/s).
-        RAFT_TRY(launch_conv3x3(wts->convc2, wts->convc2_w, 1, a, EPI_RELU, s, false, &wts->convc2_w44, 1));
+        RAFT_TRY(launch_conv3x3(wts->convc2, wts->convc2_w, 1, a, EPI_RELU, s, false, &wts->convc2_w44, raft_opt(RAFT_OPT_CONVC2_KS, 1)));
         RAFT_MARK();
     }
     if (ov) RAFT_HIP(hipStreamWaitEvent(sf, ov->e_fh, 0));   // flow of the previous iteration is final
@@ -744,7 +744,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     {   // flo = relu(convf2(flo))             3x3, 128 -> 64    -> corflo[:, 192:256]
         ConvArgs a = conv_args(wts->convf2, flo1, 128, 128, nullptr, 0, 0, B, h, w, 64, corflo + 192, 256);
-        RAFT_TRY(launch_conv3x3(wts->convf2, wts->convf2_w, 2, a, EPI_RELU, sf));
+        RAFT_TRY(launch_conv3x3(wts->convf2, wts->convf2_w, 2, a, EPI_RELU, sf, false, &wts->convf2_w44));
         RAFT_MARK();
     }
     if (ov) {

@@ -345,7 +345,8 @@ def pack_basic_update(weights: Dict[str, np.ndarray], prefix: str = 'update_bloc
     for field, kk, bb_ in (('convc2_w44', w[f'{p}/encoder/convc2/kernel'], w[f'{p}/encoder/convc2/bias']),
                            ('conv_w44', w[f'{p}/encoder/conv/kernel'], w[f'{p}/encoder/conv/bias']),
                            ('fh1_mask0_w44', k, b),
-                           ('fh1_w44', w[f'{p}/flow_head/conv1/kernel'], w[f'{p}/flow_head/conv1/bias'])):
+                           ('fh1_w44', w[f'{p}/flow_head/conv1/kernel'], w[f'{p}/flow_head/conv1/bias']),
+                           ('convf2_w44', w[f'{p}/encoder/convf2/kernel'], w[f'{p}/encoder/convf2/bias'])):
         wp, bb, npad = pack_conv_winograd4(kk, bb_)
         out.append((field, wp, bb, npad))
     return out
