@@ -60,19 +60,19 @@ WINOGRAD_ALGORITHMS = {2.25: 'Winograd F(2x2,3x3)', 4.0: 'Winograd F(4x4,3x3)', 
 def winograd_layers(pairs=4):
     """{stage name: direct MACs / executed MACs} of the stages that are on a Winograd kernel under the current
     RAFT_CONV_WINO / RAFT_CONV_WINO4 / RAFT_GRU_WINO / RAFT_GRU_WINO4 switches (defaults of csrc/conv.hip: F(2x2,3x3) mask
-    13 = convc2 | conv | fh1_mask0; F(4x4,3x3) mask 8 = fh1_mask0 from 2 pairs per launch on, + 1 = convc2 from 4, + 4 = conv from 8 on; GRU masks 15:
+    13 = convc2 | conv | fh1_mask0; F(4x4,3x3) mask 8 = fh1_mask0 from 2 pairs per launch on, + 1 | 2 = convc2, convf2 from 4, + 4 = conv from 8 on; GRU masks 15:
     F(4, 5) where its bit is set, else F(2, 5))."""
     from tf_raft_amd import _ffi
     m3 = int(_ffi.get_option('RAFT_CONV_WINO') or 13)
     m44 = _ffi.get_option('RAFT_CONV_WINO4')
-    m44 = int(m44) if m44 else (0 if pairs < 2 else 8 | (1 if pairs >= 4 else 0) | (4 if pairs >= 8 else 0))
+    m44 = int(m44) if m44 else (0 if pairs < 2 else 8 | (3 if pairs >= 4 else 0) | (4 if pairs >= 8 else 0))
     mg = int(_ffi.get_option('RAFT_GRU_WINO') or 15)
     mg4 = int(_ffi.get_option('RAFT_GRU_WINO4') or 15)
     on = {}
     for bit, name in ((1, 'convc2'), (2, 'convf2'), (4, 'conv'), (8, 'fh1_mask0')):
         if m3 & bit:
             on[name] = 2.25
-        if (m44 & bit) and name != 'convf2':
+        if m44 & bit:
             on[name] = 4.0
     for bit, name in ((1, 'gru_zr1'), (2, 'gru_q1'), (4, 'gru_zr2'), (8, 'gru_q2')):
         if mg4 & bit:
@@ -536,16 +536,18 @@ def main():
                 roof['direct_conv_flops_per_launch'] = flops[dom]
                 roof['algorithmic_tflops'] = round(alg, 2)    # direct-convolution FLOPs / time: may exceed the peak
                 roof['frac_algorithmic'] = round(alg / PEAK_FP32_MFMA_TFLOPS, 4)
-            if ratio == 4.0 and dom == 'convc2':
-                # convc2 on F(4x4) runs 8 x 64-pixel x 64-channel workgroups WITHOUT the K split (csrc/conv.hip): fewer than the
-                # chip has CUs at small batches, by choice -- the launch takes 18 % less CU-time than the K-split one and the
-                # flow / mask branches of the three-stream loop run on the CUs it leaves free (same-box A/B in DESIGN 4.5).  The
-                # whole-chip fraction above is therefore low by construction; the fraction on the CUs it occupies is beside it
-                wgs = B * ((h + 7) // 8) * ((w + 63) // 64) * 3
+            if ratio == 4.0 and dom in ('convc2', 'fh1_mask0', 'conv', 'convf2'):
+                # launch geometry of the F(4x4) kernel (csrc/conv_wino4.hip): 8 x 64-pixel x 64-channel workgroups, or K-split
+                # 4 x 64-pixel ones while those would be fewer than 128; one workgroup per CU.  At 448 x 512 the counts are
+                # 7 * 2^k: a single round of workgroups that leaves CUs to the side branches of the three-stream loop
+                # (DESIGN 4.5 / 4.6), so the whole-chip fraction above has the occupied-CU fraction beside it
+                nb = {'convc2': 3, 'fh1_mask0': 8, 'conv': 2, 'convf2': 1}[dom]
+                grid1 = B * ((h + 7) // 8) * ((w + 63) // 64) * nb
+                ksplit = grid1 < 128
+                wgs = B * ((h + 3) // 4) * ((w + 63) // 64) * nb if ksplit else grid1
                 occ = min(1.0, wgs / 256.0)
-                roof['launch'] = {'workgroups': wgs, 'cus': 256, 'occupied_cu_frac': round(occ, 4),
-                                  'frac_on_occupied_cus': round(ach / PEAK_FP32_MFMA_TFLOPS / occ, 4),
-                                  'note': 'one workgroup per CU; the side branches of the three-stream loop use the other CUs'}
+                roof['launch'] = {'workgroups': wgs, 'k_split': ksplit, 'cus': 256, 'occupied_cu_frac': round(occ, 4),
+                                  'frac_on_occupied_cus': round(ach / PEAK_FP32_MFMA_TFLOPS / occ, 4)}
         else:
             ach = bytes_[dom] / (stage_ms[dom] * 1e-3) / 1e9
             tr, note = pmc_traffic(dom, B)

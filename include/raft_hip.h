@@ -28,8 +28,8 @@
  *                       (0..5 legacy (tap, chunk)-stepped tiles; 100 + 10*TH + TN halo tiles, TH in {4,7,8})
  *   RAFT_CONV_DEEP      0/1  deep weight prefetch of the single-column-block halo tiles          (default 1)
  *   RAFT_CONV_WINO      bit mask {1 convc2, 2 convf2, 4 conv, 8 fh1_mask0}: layers on the F(2x2,3x3) kernel (13)
- *   RAFT_CONV_WINO4     the same mask for the F(4x4,3x3) kernel, preferred where its bit is set and the 6x6-tap weights
- *                       were supplied        (default by launch size: 0 for a single 448x512 pair, 8 = fh1_mask0 from 2 pairs, + 1 = convc2 from 4, + 4 = conv from 8)
+ *   RAFT_CONV_WINO4     the same mask (bit 2 = convf2) for the F(4x4,3x3) kernel, preferred where its bit is set and the 6x6-tap weights
+ *                       were supplied        (default by launch size: 0 for a single 448x512 pair, 8 = fh1_mask0 from 2 pairs, + 1 | 2 = convc2, convf2 from 4, + 4 = conv from 8)
  *   RAFT_WINO4_KS       1/2  F(4x4,3x3) kernel: 8 x 64-pixel workgroups / 4 x 64-pixel workgroups with K split between two
  *                            wave sets                                                        (default: by grid size)
  *   RAFT_SMALL_WINO     bit mask {1 conv, 2 gru_zr, 4 gru_q, 8 fh1} of the SmallUpdateBlock      (default 15)
@@ -51,7 +51,7 @@
  *                            the main stream instead of four ([fh1 | mask.0] and the mask branch's flow alternate between two buffers) (default 1)
  *   RAFT_MASK_BG_WGS    workgroups of the mask + upsampling kernel in the three-stream loop's iterations 0 .. n-2 (each walks
  *                       several tiles; 0 = one workgroup per tile)     (default 32; 0 where the chain's launches fill all CUs exactly)
- *   RAFT_CONVC2_KS      1/2  convc2 on the F(4x4) kernel in the loops: 8-row workgroups / K-split 4-row workgroups   (default 1)
+ *   RAFT_CONVC2_KS      1/2  convc2 on the F(4x4) kernel in the loops: 8-row workgroups / K-split 4-row workgroups   (default: by grid size)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)

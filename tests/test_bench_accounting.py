@@ -45,8 +45,10 @@ def test_winograd_layers_follow_the_library_switches():
         for k in saved:
             _ffi.set_option(k, None)
         d = bench.winograd_layers()
-        assert d == {'convc2': 4.0, 'conv': 2.25, 'fh1_mask0': 4.0, 'gru_zr1': 2.5, 'gru_q1': 2.5, 'gru_zr2': 2.5,
-                     'gru_q2': 2.5}                               # F(4x4,3x3): the flow / mask head and convc2 by default ...
+        assert d == {'convc2': 4.0, 'convf2': 4.0, 'conv': 2.25, 'fh1_mask0': 4.0, 'gru_zr1': 2.5, 'gru_q1': 2.5, 'gru_zr2': 2.5,
+                     'gru_q2': 2.5}                               # F(4x4,3x3): the flow / mask head, convc2 and convf2 by default ...
+        assert bench.winograd_layers(2) == {**{k: v for k, v in d.items() if k not in ('convc2', 'convf2')}, 'convc2': 2.25}
+        assert bench.winograd_layers(1)['fh1_mask0'] == 2.25      # a single pair: F(2x2) everywhere
         assert bench.winograd_layers(8)['conv'] == 4.0            # ... and conv from 8 pairs per launch on
         _ffi.set_option('RAFT_CONV_WINO4', 0)
         assert bench.winograd_layers(8)['conv'] == 2.25 and bench.winograd_layers()['fh1_mask0'] == 2.25

@@ -282,9 +282,14 @@ constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr,
 // without, 133 with -- same-box A/B with bench.py, profiles/r07p_bench_mask_ab.txt: 4 pairs 270 -> 282, 8 pairs 285 -> 296);
 // at two pairs the flow / mask head alone gains (206 -> 221 pairs/s with mask 8 on two boxes; with convc2 as well 214 and one
 // outlier of 235: profiles/r08k_round3_options.txt, r08z_b2_options.txt).
+// Bit 2 = convf2 (3x3, 128 -> 64) from 4 pairs on: alone its 56 K-split workgroups (4 pairs) are slower than the direct kernel's
+// 224 (42 against 27 us), but they take a quarter of the CU-time and, with 108 KB of LDS each, settle on CUs of their own: in the
+// three-stream loop convc2's 168 K-split workgroups + these 56 + the 32 of the background mask branch are exactly 256 -- the flow
+// branch no longer competes with convc2, which can have its faster shape back (one process, profiles/r09i_b4_options3.txt:
+// 303.1 pairs/s -> 325.9 at 4 pairs; with convc2 on 8-row workgroups 303.3; 8 pairs 345.0 -> 353.3).
 static int wino4_default_mask(const ConvArgs &a) {
     const int64_t m = (int64_t)a.B * a.H * a.W;
-    return m < 2 * 3584 ? 0 : (8 | (m >= 4 * 3584 ? 1 : 0) | (m >= 8 * 3584 ? 4 : 0));
+    return m < 2 * 3584 ? 0 : (8 | (m >= 4 * 3584 ? 1 | 2 : 0) | (m >= 8 * 3584 ? 4 : 0));
 }
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
                           hipStream_t s, bool small = false, const raft_conv_weights *wino44 = nullptr, int w4_ks_hint = 0) {
@@ -727,12 +732,12 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     {   // cor = relu(convc2(cor))             3x3, 256 -> 192   -> corflo[:, 0:192]
         ConvArgs a = conv_args(wts->convc2, cor1, 256, 256, nullptr, 0, 0, B, h, w, 192, corflo, 256);
-        // F(4x4): 8-row workgroups without the K split even where they are fewer than half the CUs (84 at 4 pairs).  Alone the
-        // K-split launch is faster (61 against 99 us), but it occupies 168 CUs for 61 us where this one takes 84 for 99: 18 % less
-        // CU-time, and in the loop the flow branch and the mask branch run on the CUs it leaves free -- same box, one process
-        // (profiles/r08n_b4_options.txt): 288.7 -> 293.7 pairs/s at 4 pairs.  Every loop uses the same shape (the loops stay
-        // bit-identical to each other); flow_head.conv1 of the final-only loop keeps the grid rule (316 against 309 pairs/s).
-        RAFT_TRY(launch_conv3x3(wts->convc2, wts->convc2_w, 1, a, EPI_RELU, s, false, &wts->convc2_w44, raft_opt(RAFT_OPT_CONVC2_KS, 1)));
+        // F(4x4) workgroup shape: the launcher's grid rule (K-split 4-row workgroups while 8-row ones would be fewer than 128: 168
+        // instead of 84 at 4 pairs).  While the flow branch ran the direct convf2 (224 workgroups competing for the same CUs) the
+        // 8-row shape was the better one in the loop (288.7 -> 293.7 pairs/s: less CU-time, room for the side branches,
+        // profiles/r08n_b4_options.txt); with convf2 on its own 56 CUs (wino4_default_mask) the K-split shape wins by 7 %.
+        // RAFT_CONVC2_KS = 1 / 2 forces either; every loop uses the same shape (the loops stay bit-identical to each other).
+        RAFT_TRY(launch_conv3x3(wts->convc2, wts->convc2_w, 1, a, EPI_RELU, s, false, &wts->convc2_w44, raft_opt(RAFT_OPT_CONVC2_KS, 0)));
         RAFT_MARK();
     }
     if (ov) RAFT_HIP(hipStreamWaitEvent(sf, ov->e_fh, 0));   // flow of the previous iteration is final
