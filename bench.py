@@ -60,12 +60,12 @@ WINOGRAD_ALGORITHMS = {2.25: 'Winograd F(2x2,3x3)', 4.0: 'Winograd F(4x4,3x3)', 
 def winograd_layers(pairs=4):
     """{stage name: direct MACs / executed MACs} of the stages that are on a Winograd kernel under the current
     RAFT_CONV_WINO / RAFT_CONV_WINO4 / RAFT_GRU_WINO / RAFT_GRU_WINO4 switches (defaults of csrc/conv.hip: F(2x2,3x3) mask
-    13 = convc2 | conv | fh1_mask0; F(4x4,3x3) mask 8 = fh1_mask0 from 2 pairs per launch on, + 1 | 2 = convc2, convf2 from 4, + 4 = conv from 8 on; GRU masks 15:
+    13 = convc2 | conv | fh1_mask0; F(4x4,3x3) mask 8 = fh1_mask0 from 2 pairs per launch on, + 1 | 2 = convc2, convf2 from 3, + 4 = conv from 8 on; GRU masks 15:
     F(4, 5) where its bit is set, else F(2, 5))."""
     from tf_raft_amd import _ffi
     m3 = int(_ffi.get_option('RAFT_CONV_WINO') or 13)
     m44 = _ffi.get_option('RAFT_CONV_WINO4')
-    m44 = int(m44) if m44 else (0 if pairs < 2 else 8 | (3 if pairs >= 4 else 0) | (4 if pairs >= 8 else 0))
+    m44 = int(m44) if m44 else (0 if pairs < 2 else 8 | (3 if pairs >= 3 else 0) | (4 if pairs >= 8 else 0))
     mg = int(_ffi.get_option('RAFT_GRU_WINO') or 15)
     mg4 = int(_ffi.get_option('RAFT_GRU_WINO4') or 15)
     on = {}

@@ -29,7 +29,7 @@
  *   RAFT_CONV_DEEP      0/1  deep weight prefetch of the single-column-block halo tiles          (default 1)
  *   RAFT_CONV_WINO      bit mask {1 convc2, 2 convf2, 4 conv, 8 fh1_mask0}: layers on the F(2x2,3x3) kernel (13)
  *   RAFT_CONV_WINO4     the same mask (bit 2 = convf2) for the F(4x4,3x3) kernel, preferred where its bit is set and the 6x6-tap weights
- *                       were supplied        (default by launch size: 0 for a single 448x512 pair, 8 = fh1_mask0 from 2 pairs, + 1 | 2 = convc2, convf2 from 4, + 4 = conv from 8)
+ *                       were supplied        (default by launch size: 0 for a single 448x512 pair, 8 = fh1_mask0 from 2 pairs, + 1 | 2 = convc2, convf2 from 3, + 4 = conv from 8)
  *   RAFT_WINO4_KS       1/2  F(4x4,3x3) kernel: 8 x 64-pixel workgroups / 4 x 64-pixel workgroups with K split between two
  *                            wave sets                                                        (default: by grid size)
  *   RAFT_SMALL_WINO     bit mask {1 conv, 2 gru_zr, 4 gru_q, 8 fh1} of the SmallUpdateBlock      (default 15)

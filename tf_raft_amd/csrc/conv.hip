@@ -282,14 +282,14 @@ constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr,
 // without, 133 with -- same-box A/B with bench.py, profiles/r07p_bench_mask_ab.txt: 4 pairs 270 -> 282, 8 pairs 285 -> 296);
 // at two pairs the flow / mask head alone gains (206 -> 221 pairs/s with mask 8 on two boxes; with convc2 as well 214 and one
 // outlier of 235: profiles/r08k_round3_options.txt, r08z_b2_options.txt).
-// Bit 2 = convf2 (3x3, 128 -> 64) from 4 pairs on: alone its 56 K-split workgroups (4 pairs) are slower than the direct kernel's
+// Bit 2 = convf2 (3x3, 128 -> 64), with convc2 from 3 pairs on: alone its 56 K-split workgroups (4 pairs) are slower than the direct kernel's
 // 224 (42 against 27 us), but they take a quarter of the CU-time and, with 108 KB of LDS each, settle on CUs of their own: in the
 // three-stream loop convc2's 168 K-split workgroups + these 56 + the 32 of the background mask branch are exactly 256 -- the flow
 // branch no longer competes with convc2, which can have its faster shape back (one process, profiles/r09i_b4_options3.txt:
 // 303.1 pairs/s -> 325.9 at 4 pairs; with convc2 on 8-row workgroups 303.3; 8 pairs 345.0 -> 353.3).
 static int wino4_default_mask(const ConvArgs &a) {
     const int64_t m = (int64_t)a.B * a.H * a.W;
-    return m < 2 * 3584 ? 0 : (8 | (m >= 4 * 3584 ? 1 | 2 : 0) | (m >= 8 * 3584 ? 4 : 0));
+    return m < 2 * 3584 ? 0 : (8 | (m >= 3 * 3584 ? 1 | 2 : 0) | (m >= 8 * 3584 ? 4 : 0));   // three pairs: 250 -> 262 pairs/s with 11, two: 237 -> 231
 }
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
                           hipStream_t s, bool small = false, const raft_conv_weights *wino44 = nullptr, int w4_ks_hint = 0) {
