@@ -749,7 +749,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     {   // flo = relu(convf2(flo))             3x3, 128 -> 64    -> corflo[:, 192:256]
         ConvArgs a = conv_args(wts->convf2, flo1, 128, 128, nullptr, 0, 0, B, h, w, 64, corflo + 192, 256);
-        RAFT_TRY(launch_conv3x3(wts->convf2, wts->convf2_w, 2, a, EPI_RELU, sf, false, &wts->convf2_w44));
+        RAFT_TRY(launch_conv3x3(wts->convf2, wts->convf2_w, 2, a, EPI_RELU, sf, false, &wts->convf2_w44, raft_opt(RAFT_OPT_CONVF2_KS, 0)));
         RAFT_MARK();
     }
     if (ov) {
