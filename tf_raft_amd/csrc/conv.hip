@@ -749,7 +749,11 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     }
     {   // flo = relu(convf2(flo))             3x3, 128 -> 64    -> corflo[:, 192:256]
         ConvArgs a = conv_args(wts->convf2, flo1, 128, 128, nullptr, 0, 0, B, h, w, 64, corflo + 192, 256);
-        RAFT_TRY(launch_conv3x3(wts->convf2, wts->convf2_w, 2, a, EPI_RELU, sf, false, &wts->convf2_w44, raft_opt(RAFT_OPT_CONVF2_KS, 0)));
+        // F(4x4) shape: K-split workgroups up to 4 pairs (28 eight-row workgroups -> 56), eight-row ones from 56 on (8 pairs:
+        // 56 of them beside convc2's 168 and the mask branch's 32: 353.4 -> 356.1 pairs/s, profiles/r09k_b8_options.txt)
+        const int f2_grid1 = B * ((h + 7) / 8) * ((w + 63) / 64);
+        RAFT_TRY(launch_conv3x3(wts->convf2, wts->convf2_w, 2, a, EPI_RELU, sf, false, &wts->convf2_w44,
+                                raft_opt(RAFT_OPT_CONVF2_KS, f2_grid1 >= 56 ? 1 : 0)));
         RAFT_MARK();
     }
     if (ov) {
