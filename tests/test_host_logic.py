@@ -434,6 +434,26 @@ def test_running_mean_mirrors_keras_mean():
     assert m.result() == 0.0 and m.count == 0
 
 
+def test_deferred_weight_gradients_keep_one_geometry_per_layer():
+    """grad.WgradDefer (the update block's weight gradients once per training step over all loop iterations): applications
+    added under one key must share kernel shape and tensor geometry -- the multi-segment kernel indexes every segment alike --
+    and a key keeps its trimming rule (padded channel counts are cut back when the gradients are assembled)."""
+    import torch
+    from tf_raft_amd import grad
+    d = grad.WgradDefer()
+    x, dy = torch.zeros((2, 6, 8, 16)), torch.zeros((2, 6, 8, 32))
+    d.add('layer', x, dy, (3, 3, 16, 32))
+    d.add('layer', x.clone(), dy.clone(), (3, 3, 16, 32))
+    assert len(d.jobs['layer']['xs']) == 2 and d.jobs['layer']['trim'] is None
+    with pytest.raises(ValueError, match='geometry'):
+        d.add('layer', torch.zeros((2, 6, 9, 16)), dy, (3, 3, 16, 32))
+    with pytest.raises(ValueError, match='geometry'):
+        d.add('layer', x, dy, (1, 1, 16, 32))
+    d.add(('zr', 'update_block', '1', 128), x, dy, (1, 5, 16, 32), trim=(14, 30))
+    assert d.jobs[('zr', 'update_block', '1', 128)]['trim'] == (14, 30)
+    assert grad.WgradDefer.MAX_SEG == 32                           # WG_MAXSEG of csrc/backward.hip: pointer pairs per launch
+
+
 def test_product_package_never_imports_the_oracle():
     """The oracle is test infrastructure; nothing under tf_raft_amd/ or tf_raft/ may reference it."""
     for pkg in ('tf_raft_amd', 'tf_raft'):
