@@ -116,6 +116,13 @@ def test_pack_update_blocks_cover_every_struct_field():
     assert not zr[1].any()                                           # the biases ride in the context convolution
     ctx = dict((f, (wp, b, n)) for f, wp, b, n in basic)['gru_ctx1']
     assert ctx[0].shape == (5, 32, 384, 4) and ctx[2] == 384         # inp rows -> [z | r | q]
+    # F(4x4, 3x3) copies in the kernel's consumption order: (Cin / 16, 72 slots, 4, npad / 32, 16, 2, 2)
+    by = dict((f, (wp, b, n)) for f, wp, b, n in basic)
+    for field, cin, cout in (('convc2_w44', 256, 192), ('convf2_w44', 128, 64), ('conv_w44', 256, 126), ('fh1_mask0_w44', 128, 512),
+                             ('fh1_w44', 128, 256)):
+        wp, b, npad = by[field]
+        assert npad == packing.round_up(cout, 64) and wp.shape == (cin // 16, 72, 4, npad // 32, 16, 2, 2), field
+        assert b.shape == (npad,) and not b[cout:].any()
     small = packing.pack_small_update(wm.init_weights('small', 0))
     assert [f for f, *_ in small] == [n for n, _ in _ffi.SmallUpdateWeights._fields_]
     szr = dict((f, (wp, b, n)) for f, wp, b, n in small)['gru_zr']
