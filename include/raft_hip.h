@@ -53,6 +53,7 @@
  *                       several tiles; 0 = one workgroup per tile)     (default 32; 0 where the chain's launches fill all CUs exactly)
  *   RAFT_CONVC2_KS      1/2  convc2 on the F(4x4) kernel in the loops: 8-row workgroups / K-split 4-row workgroups   (default: by grid size)
  *   RAFT_CONVF2_KS      1/2  the same for convf2                             (default: K-split below 56 eight-row workgroups)
+ *   RAFT_GRU_Q_TNW      1/2  32- / 64-channel workgroups of the F(4,5) candidate-state convolutions            (default: by grid size)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)

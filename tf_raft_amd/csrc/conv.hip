@@ -254,7 +254,7 @@ static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weig
         a.wp = wino4.wp;
         a.bias = wino4.bias;
         a.npad = wino4.npad;
-        return raft_launch_conv_wino1d(a, kh, kw, epi, s, 4);
+        return raft_launch_conv_wino1d(a, kh, kw, epi, s, 4, epi == EPI_GRU_Q ? raft_opt(RAFT_OPT_GRU_Q_TNW, 0) : 0);
     }
     if ((mask & bit) && wino.wp != nullptr) {
         a.wp = wino.wp;

@@ -350,4 +350,5 @@ __global__ void __launch_bounds__(256, 2) conv_wino1d_kernel(ConvArgs p) {
 
 // launcher (conv_wino1d.hip): kh x kw = 1x5 or 5x1; mo = 2: F(2, 5), `a.wp` holds G' g packed as a 6-tap kernel; mo = 4:
 // F(4, 5), 8 taps (needs c0, c1 multiples of 32).  a.init / GRU epilogues as in raft_launch_conv
-int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s, int mo = 2);
+// tnw_hint = 1 / 2: the caller's choice of 32- / 64-channel workgroups where the launcher would decide by grid size
+int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s, int mo = 2, int tnw_hint = 0);

@@ -21,7 +21,7 @@ static int launch_wino1d_tm(const ConvArgs &a, int epi, int grid, int tnw, bool 
     return tnw == 2 ? launch_wino1d<AXIS, 2, 1, TM>(a, epi, grid, s) : launch_wino1d<AXIS, 1, 1, TM>(a, epi, grid, s);
 }
 
-int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s, int mo) {
+int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStream_t s, int mo, int tnw_hint) {
     if (mo != 2 && mo != 4) return RAFT_E_UNSUPPORTED;
     if (mo == 4 && (a.c0 % 32 || a.c1 % 32)) return RAFT_E_UNSUPPORTED;
     if (!((kh == 1 && kw == 5) || (kh == 5 && kw == 1))) return RAFT_E_UNSUPPORTED;
@@ -38,7 +38,7 @@ int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStrea
         if ((int64_t)(mo + 4) * (a.c0 + a.c1) * a.npad * 4 >= lim) return RAFT_E_UNSUPPORTED;
     }
     const int axis = kh == 5 ? 1 : 0;
-    const int forced = raft_opt(RAFT_OPT_WINO_TNW, 0);   // tuning / test overrides (raft_set_option)
+    const int forced = raft_opt(RAFT_OPT_WINO_TNW, tnw_hint);   // tuning / test overrides (raft_set_option), else the caller's hint
     const int tm_forced = raft_opt(RAFT_OPT_WINO1D_TM, 0);
     const bool ck2 = a.c0 % 32 == 0 && a.c1 % 32 == 0 && raft_opt(RAFT_OPT_WINO_CK, RAFT_WINO1D_CK2_DEFAULT ? 2 : 1) == 2;
     auto tiles_of = [&](int tm) {
