@@ -1,3 +1,5 @@
+"""Round-3 option sweep at batch B (one process): convf2 on F(2x2), no K-split F(4x4) workgroups, encoder F(4x4) stage masks;
+at 8 pairs also conv off F(4x4); and predict_step with / without the K split.  python tools/b4_options.py [B]"""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import tf_raft_amd

@@ -1,3 +1,4 @@
+"""Minimal batch probe (ms per forward at a few batch sizes)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tf_raft_amd

@@ -1,3 +1,4 @@
+"""Encoder F(4x4) stage masks (RAFT_ENC_WINO4) at 4 and 8 pairs with the final loop schedule, one process."""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import tf_raft_amd

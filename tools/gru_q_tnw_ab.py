@@ -1,3 +1,4 @@
+"""32- against 64-channel workgroups of the F(4,5) candidate-state convolutions (RAFT_GRU_Q_TNW) at 4 and 8 pairs, one process."""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import tf_raft_amd

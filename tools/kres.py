@@ -1,3 +1,5 @@
+"""Registers / spills / LDS of the kernels in one object file of the library (from the code object's notes).
+usage: python tools/kres.py tf_raft_amd/lib/<unit>.hip.o [name-regex]"""
 import sys, re, subprocess, os, tempfile
 LLVM='/opt/rocm/lib/llvm/bin'
 obj=sys.argv[1]; pat=sys.argv[2] if len(sys.argv)>2 else '.'

@@ -1,3 +1,5 @@
+"""1 / 2 / 3 pairs: two-kernel mask branch against the fused kernel, one workgroup per tile or in the background (RAFT_MASK_FUSED,
+RAFT_MASK_BG_WGS), one process."""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import tf_raft_amd
