@@ -6,13 +6,20 @@ discontinuity turns rounding noise into O(1) px differences once a c
 coordinate crosses an integer.  GPU parity tests assert 1e-3 only where this file shows the oracle
 agreeing with itself to 1e-4.
 
-Two weight regimes:
+Weight regimes:
   * ``default``      Keras-default random weights (what an un-trained ``RAFT()`` holds).  The flow grows ~7 px per
                      iteration and the 448x512 trajectory is ill conditioned from iteration 10 on (reported stress test);
   * ``conditioned``  ``tf_raft_amd.weights.condition_weights``: flow head scaled + biased so that no tap coordinate can
                      cross an integer in 24 iterations.  The oracle agrees with itself to < 2e-4 on EVERY iteration, so
                      the north-star sentence (``flow_predictions[-1]`` within 1e-3 at (B,448,512,3), free-running) is
                      asserted on these cases, 3 seeds per variant.
+
+  * ``jumpN``       (round 4) the conditioned head plus an INTEGER drift ``tf_raft_amd.weights.JUMPS[N]`` per iteration: every tap
+                     coordinate keeps the conditioned regime's distance from the sampler's discontinuities (``margin`` below:
+                     min over pixels and axes of the distance of the low-resolution flow from an integer, per iteration, in the
+                     fp64 run) while its integer part moves every iteration -- lookup windows cross integers and the clamped
+                     borders at every pyramid level (|flow| 24 .. 48 low-resolution pixels after 24 iterations).  The free-running
+                     lookup-in-the-loop tests (test_jump_regime_*) are asserted on these cases with no allowance.
 
 Run from the repo root:  python tests/golden/make_conditioning.py
 """
@@ -37,6 +44,11 @@ CASES += [('small', 256, 256, 4, 0, 'conditioned'), ('raft', 1024, 1024, 3, 0, '
 CASES += [('raft', 448, 512, 24, s, 'mid') for s in (0, 1, 2, 3, 4)] + [('small', 448, 512, 24, s, 'mid') for s in (0, 1)]
 # ... and every element of the batch that test_north_star_benchmarked_batches runs (seed 3, B = 8), each alone
 BATCH_CASES = [('raft', 448, 512, 24, 3, 'conditioned', 8)]
+# round 4: integer-jump regime -- 5 RAFT seeds (5 different drift vectors), 3 SmallRAFT seeds, config 4's size for all 24
+# iterations, and every element of an 8-pair batch (seed 5 -> JUMPS[5])
+CASES += [('raft', 448, 512, 24, s, f'jump{s}') for s in (0, 1, 2, 3, 4)] + [('small', 448, 512, 24, s, f'jump{s}') for s in (0, 1, 2)]
+CASES += [('raft', 1024, 1024, 24, 0, 'jump0')]
+BATCH_CASES += [('raft', 448, 512, 24, 5, 'jump5', 8)]
 
 
 def case_key(variant, H, W, iters, seed, regime):
@@ -59,9 +71,16 @@ def run(variant, H, W, iters, seed, regime, B=1, element=0):
     i1, i2 = i1[element:element + 1], i2[element:element + 1]
     cls = oracle.RAFT if variant == 'raft' else oracle.SmallRAFT
     o32 = cls(wts, iters_pred=iters)([i1, i2])
-    o64 = cls(wts, iters_pred=iters, dtype=torch.float64)([i1, i2])
-    return dict(epe32v64=[max_epe(a, b) for a, b in zip(o32, o64)],
-                max_abs_flow=[float(np.abs(b).max()) for b in o64])
+    trace = {}
+    o64 = cls(wts, iters_pred=iters, dtype=torch.float64)([i1, i2], trace=trace)
+    out = dict(epe32v64=[max_epe(a, b) for a, b in zip(o32, o64)],
+               max_abs_flow=[float(np.abs(b).max()) for b in o64])
+    if regime.startswith('jump'):
+        # distance of the low-resolution flow from the nearest integer (level-0 units; level l: / 2^l), worst pixel and axis
+        c0 = oracle.coords_grid(1, H // 8, W // 8, torch.float64)
+        fr = [np.mod((it['coords1'] - c0).numpy(), 1.0) for it in trace['iters']]
+        out['margin'] = [float(np.minimum(f, 1.0 - f).min()) for f in fr]
+    return out
 
 
 if __name__ == '__main__':

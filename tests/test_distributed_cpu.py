@@ -170,6 +170,29 @@ def test_bench_gpus2_self_launches_without_torchrun():
     assert line['config']['global_batch'] == 2 * line['config']['pairs_per_gpu'] and 'dry_run' in line
 
 
+def test_bench_gpus8_dry_run_announces_every_rank_before_timing():
+    """The driver's 8-GPU launch shape, control flow only (RAFT_BENCH_DRY_RUN=cpu, gloo): eight ranks rendezvous on 127.0.0.1,
+    the preflight table (one entry per rank, printed to stderr BEFORE the timed region) names all of them, and rank 0's line
+    reports ranks_seen == 8 with BASELINE's full metric string."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['RAFT_BENCH_DRY_RUN'] = 'cpu'
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['ranks_seen'] == 8
+    assert line['metric'].startswith('image-pairs/sec at 448') and 'final-iter EPE' in line['metric']
+    pre = [l for l in out.stderr.splitlines() if l.startswith('[bench preflight] ')]
+    assert len(pre) == 1, out.stderr[-2000:]
+    table = json.loads(pre[0][len('[bench preflight] '):])
+    assert table['summary']['ranks_seen'] == 8 and sorted(t['rank'] for t in table['ranks']) == list(range(8))
+
+
 def test_bench_rejects_a_world_size_that_contradicts_gpus():
     import subprocess
     env = dict(os.environ, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0', RAFT_BENCH_DRY_RUN='cpu')

@@ -406,6 +406,93 @@ def test_mid_regime_free_running(variant, seeds):
         assert len(clean_seeds) >= 4 and sum(full_pass) >= 3, (clean_seeds, full_pass)
 
 
+def _jump_case(variant, H, W, seed, B=1):
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_conditioning import case_inputs
+    return case_inputs(variant, H, W, seed, f'jump{seed}', B=B)
+
+
+def _assert_jump_fixture(key, bound):
+    """The fixture entry of a jump-regime case: the oracle agrees with itself (fp32 vs fp64) within `bound` on EVERY iteration
+    and no low-resolution flow value comes within 5e-3 of an integer in any iteration (1e-5-class implementation noise cannot
+    move a tap across one of the sampler's discontinuities)."""
+    with open(os.path.join(GOLDEN, 'conditioning.json')) as f:
+        cond = json.load(f)[key]
+    assert max(cond['epe32v64']) <= bound, ('fixture: the oracle itself is ill conditioned on this case', key)
+    assert min(cond['margin']) >= 5e-3, ('fixture: a tap coordinate passes too close to an integer', key)
+    return cond
+
+
+@pytest.mark.parametrize('variant, seed', [('raft', s) for s in range(5)] + [('small', s) for s in range(3)])
+def test_jump_regime_free_running_lookup_in_the_loop(variant, seed):
+    """The lookup INSIDE the free-running recurrence (reference corr.py:41-68, 116-152 under model.py:93-109), no allowance:
+    tf_raft_amd.weights.JUMP_HEAD + JUMPS[seed] moves the low-resolution flow by an integer vector per iteration on top of the
+    conditioned regime's sub-pixel trajectory, so that in EVERY iteration every lookup window sits at new integer positions
+    at every pyramid level, slides over the clamped borders (|flow| 24 .. 48 px on a 56 x 64 map: level 0 windows of half
+    the pixels are entirely outside the map in the last iterations, levels 1-3 partly) and the coarse levels are sampled far
+    from the identity -- while no tap coordinate ever comes near a discontinuity (fixture: margin >= 5e-3, oracle fp32 vs
+    fp64 <= 2e-4 (RAFT) / 3e-4 (SmallRAFT: flow values up to 390 px, one fp32 ulp = 3e-5) on all 24 iterations).  Asserted on
+    ALL 24 predictions of EVERY seed: max-abs EPE <= 1e-3."""
+    import oracle
+    import tf_raft_amd
+    cond = _assert_jump_fixture(f'{variant}_448x512_seed{seed}_it24_jump{seed}', 2e-4 if variant == 'raft' else 3e-4)
+    i1, i2, wts = _jump_case(variant, 448, 512, seed)
+    ocls, dcls = (oracle.RAFT, tf_raft_amd.RAFT) if variant == 'raft' else (oracle.SmallRAFT, tf_raft_amd.SmallRAFT)
+    want = ocls(wts, iters_pred=24)([i1, i2])
+    got = dcls(weights=wts, iters_pred=24)([i1, i2])
+    errs = [_max_epe(_np(g), w) for g, w in zip(got, want)]
+    lo = want[-1] / 8.0
+    report(f'jump regime {variant} seed {seed}', final_epe=errs[-1], worst_epe=max(errs), oracle32_vs_64_worst=max(cond['epe32v64']),
+           margin=min(cond['margin']), flow_x_range=(float(lo[..., 0].min()), float(lo[..., 0].max())),
+           flow_y_range=(float(lo[..., 1].min()), float(lo[..., 1].max())))
+    print('[parity] per-iteration max EPE hip-vs-oracle32 :', ' '.join(f'{e:.1e}' for e in errs))
+    assert len(got) == 24
+    assert max(errs) <= TOL, (seed, errs)
+    last = dcls(weights=wts, iters_pred=24).predict_step((i1, i2))
+    assert _max_epe(_np(last), want[-1]) <= TOL
+
+
+def test_jump_regime_benchmarked_batches():
+    """The same regime at the benchmarked batch shapes (B = 4 = BASELINE configs[1], B = 8 = configs[2] per GPU; 2 where the
+    fused background mask branch starts): every element against the oracle run on that element ALONE, all 24 predictions
+    within 1e-3, no allowance."""
+    import oracle
+    import tf_raft_amd
+    for b in range(8):
+        _assert_jump_fixture(f'raft_448x512_seed5_it24_jump5_batch8_element{b}', 2e-4)
+    i1, i2, wts = _jump_case('raft', 448, 512, 5, B=8)
+    want = [oracle.RAFT(wts, iters_pred=24)([i1[b:b + 1], i2[b:b + 1]]) for b in range(8)]
+    for B in (2, 4, 8):
+        got = tf_raft_amd.RAFT(weights=wts, iters_pred=24)([i1[:B], i2[:B]])
+        worst = 0.0
+        for b in range(B):
+            errs = [_max_epe(_np(g)[b:b + 1], w) for g, w in zip(got, want[b])]
+            worst = max(worst, max(errs))
+            assert max(errs) <= TOL, (B, b, errs)
+        report(f'jump regime raft 448x512 B={B}', worst_epe_any_iteration_any_element=worst)
+
+
+def test_jump_regime_alternate_corr_1024_all_24_iterations():
+    """BASELINE config 4 for the whole loop: (1,1024,1024,3), 24 free-running iterations in the jump regime (flow drifts to
+    (+24, -24) low-resolution pixels: the on-demand kernel's union boxes move across the 128 x 128 map and over its borders),
+    volume-free HIP path AND stored-volume HIP path against the oracle's stored-volume forward; 1e-3 on every prediction."""
+    import oracle
+    import tf_raft_amd
+    _assert_jump_fixture('raft_1024x1024_seed0_it24_jump0', 2.5e-4)
+    i1, i2, wts = _jump_case('raft', 1024, 1024, 0)
+    want = oracle.RAFT(wts, iters_pred=24)([i1, i2])
+    got = tf_raft_amd.RAFT(weights=wts, iters_pred=24, alternate_corr=True)([i1, i2])
+    errs = [_max_epe(_np(g), w) for g, w in zip(got, want)]
+    report('jump regime, alternate corr 1024x1024, 24 iterations', final_epe=errs[-1], worst_epe=max(errs))
+    assert max(errs) <= TOL, errs
+    del got
+    vol = tf_raft_amd.RAFT(weights=wts, iters_pred=24)([i1, i2])
+    errs_v = [_max_epe(_np(g), w) for g, w in zip(vol, want)]
+    report('jump regime, stored volume 1024x1024, 24 iterations', final_epe=errs_v[-1], worst_epe=max(errs_v))
+    assert max(errs_v) <= TOL, errs_v
+
+
 def test_winograd_noise_is_tracked_on_the_default_weight_horizon(raft_opt):
     """the Winograd kernels are a noisier fp32 algorithm than the direct ones; what that costs is measured, not
     assumed.  Keras-default weights at (1,448,512,3) (the ill-conditioned stress case: flow grows ~7 px per iteration):
@@ -595,7 +682,7 @@ def test_rotating_buffer_loop_is_bitwise_the_single_stream_loop(shape, iters, ra
     import tf_raft_amd
     B, H, W = shape
     i1, i2, wts = _conditioned_case('raft', H, W, 2, B=B)
-    raft_opt.set('RAFT_MASK_FUSED', '1')          # the schedule belongs to the fused mask kernel (default only from 4 pairs on)
+    raft_opt.set('RAFT_MASK_FUSED', '1')          # the schedule belongs to the fused mask kernel (default from 2 pairs on)
     ref = [_np(p) for p in tf_raft_amd.RAFT(weights=wts, iters_pred=iters, overlap=False)([i1, i2])]
     for opt in ('1', '0'):
         raft_opt.set('RAFT_LOOP_ROTATE', opt)

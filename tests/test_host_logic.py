@@ -493,6 +493,12 @@ def test_a_stale_library_is_never_loaded_silently(monkeypatch):
     monkeypatch.setattr(build, 'built_digest', build.source_digest)
     with pytest.warns(RuntimeWarning, match='up-to-date'):
         _ffi.load_library()
+    # a prebuilt .so that arrived WITHOUT its stamp (box without hipcc) cannot be verified: it loads with a
+    # warning that says so, and the ABI check still applies
+    monkeypatch.setattr(_ffi, '_LIB', None)
+    monkeypatch.setattr(build, 'built_digest', lambda: None)
+    with pytest.warns(RuntimeWarning, match='UNVERIFIED'):
+        assert _ffi.load_library().raft_version() == _ffi.ABI_VERSION
 
 
 def _wino4_emulate(x, wp, bias, cout):

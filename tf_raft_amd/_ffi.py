@@ -152,8 +152,11 @@ def library_path() -> str:
 
 def load_library():
     """Load and type the library.  When hipcc is available the build is refreshed first (a digest of sources + flags
-    makes that a no-op for an up-to-date .so), so a stale library never meets newer struct mirrors; without hipcc the
-    prebuilt .so is used as is.  Either way ``raft_version()`` must equal ``ABI_VERSION``."""
+    makes that a no-op for an up-to-date .so), so a stale library never meets newer struct mirrors.  When the refresh
+    fails (no hipcc, read-only tree, compile error) an existing .so is used only if its build stamp (lib/build.sha256,
+    shipped beside it) matches the sources on disk; a .so WITHOUT a stamp cannot be verified and is loaded with a warning
+    (the ABI check below still applies); a stamp that names other sources is refused unless RAFT_ALLOW_STALE_LIB=1.
+    Either way ``raft_version()`` must equal ``ABI_VERSION``."""
     global _LIB
     if _LIB is not None:                       # fast path: no lock once loaded
         return _LIB
@@ -171,14 +174,17 @@ def load_library():
                     'the RAFT device path has no CPU fallback') from exc
             # A library exists but the refresh failed (compile error, no hipcc, read-only tree).  It may only be used
             # if it was built from exactly these sources; anything else would run old kernels under new tests.
-            stale = _build.built_digest() != _build.source_digest()
+            built = _build.built_digest()
+            unknown = built is None                          # prebuilt .so without its stamp: nothing to compare
+            stale = (not unknown) and built != _build.source_digest()
             if stale and os.environ.get('RAFT_ALLOW_STALE_LIB') != '1':
                 raise RuntimeError(
                     f'{path} was built from different sources than the ones on disk and rebuilding failed: {exc}.  '
                     'Fix the build, or set RAFT_ALLOW_STALE_LIB=1 to load the old library knowingly') from exc
             import warnings
             warnings.warn(f'libraft_hip.so could not be refreshed ({exc}); loading the existing '
-                          f'{"STALE " if stale else "up-to-date "}library at {path}', RuntimeWarning, stacklevel=2)
+                          f'{"STALE " if stale else ("UNVERIFIED (no build stamp) " if unknown else "up-to-date ")}library at {path}',
+                          RuntimeWarning, stacklevel=2)
         try:
             lib = C.CDLL(path)
         except OSError as exc:

@@ -78,7 +78,13 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+# True after a call of build_library() in this process that compiled (False: the existing library was up to date).
+# bench.py's multi-GPU preflight reports it per rank: on a box that received the prebuilt .so no rank should compile.
+LAST_BUILD_COMPILED = False
+
+
 def _build_locked(force: bool, verbose: bool) -> str:
+    global LAST_BUILD_COMPILED
     srcs, hdrs = _inputs()
     stamp = os.path.join(LIBDIR, 'build.sha256')
     digest = _digest(srcs + hdrs)
@@ -107,6 +113,7 @@ def _build_locked(force: bool, verbose: bool) -> str:
     os.replace(tmp, LIBPATH)
     with open(stamp, 'w') as f:
         f.write(digest)
+    LAST_BUILD_COMPILED = True
     return LIBPATH
 
 

@@ -24,25 +24,40 @@ def _f32(t):
     return _dev.to_device(t).as_subclass(torch.Tensor).to(torch.float32).contiguous()
 
 
-# Packed-weight cache of one training step: the functional path packs Keras-layout kernels on the host for the generic
-# convolution kernels; within a step the same kernel is used by every loop iteration (forward, and flipped for the input
-# gradient).  Keyed by the identity of the source array, which is kept alive by the entry; ``clear_pack_cache()`` is called by
-# ``RAFT.train_step`` at the start of every step (the optimizer replaces the arrays).
+# Packed-weight cache of one training step: the functional path packs Keras-layout kernels for the generic convolution
+# kernels; within a step the same kernel is used by every loop iteration (forward, and flipped for the input gradient).
+# Keyed by the identity of the source array (kept alive by the entry) AND validated against a version: parameters may be
+# device tensors that the optimizer and the batch-norm statistics update IN PLACE, so identity alone would hand back the
+# packed copy of the old values.  The version of an entry is (torch's in-place counter of each source tensor, the module
+# counter that ``bump_pack_version()`` advances); ``training.AdamW.apply_gradients`` and the moving-statistics update call
+# ``bump_pack_version()`` after writing through raw pointers (HIP kernels do not advance torch's counter), and
+# ``RAFT.train_step`` still clears the cache at the start of every step to bound its size.
 _PACK = {}
+_PACK_VERSION = [0]
 
 
 def clear_pack_cache():
     _PACK.clear()
 
 
+def bump_pack_version():
+    """Call after parameters were modified in place outside torch (optimizer / statistics kernels): invalidates every entry."""
+    _PACK_VERSION[0] += 1
+
+
+def _version_of(a):
+    return a._version if isinstance(a, torch.Tensor) else 0
+
+
 def _cached(arr, tag, make, also=None):
-    """``make()`` memoised on the identity of ``arr`` (and of ``also``); both are kept alive by the entry."""
+    """``make()`` memoised on the identity of ``arr`` (and of ``also``) and on their versions; both are kept alive by the entry."""
     key = (id(arr), id(also), tag)
     if len(_PACK) > 2048:                    # callers outside train_step never clear: keep the cache bounded
         _PACK.clear()
+    ver = (_version_of(arr), _version_of(also), _PACK_VERSION[0])
     hit = _PACK.get(key)
-    if hit is None or hit[0] is not arr or hit[1] is not also:
-        hit = (arr, also, make())
+    if hit is None or hit[0] is not arr or hit[1] is not also or hit[3] != ver:
+        hit = (arr, also, make(), ver)
         _PACK[key] = hit
     return hit[2]
 

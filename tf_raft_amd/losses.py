@@ -138,7 +138,27 @@ class Mean:
         self.count += 1
 
     def result(self):
+        """Running mean.  Fed device scalars (train_step / test_step) it is a 0-dim DEVICE tensor -- like the Keras metric's
+        tensor, no host synchronisation inside a step -- otherwise a Python float (0.0 when nothing was fed: keras
+        divide_no_nan).  ``float(m.result())`` works on both (and synchronises); logging code that wants plain numbers
+        (``json.dumps``, formatting) uses ``result_float()`` or ``losses.to_floats(logs)``."""
         if not self.count:
             return 0.0                                              # keras: divide_no_nan
         mean = self.total / self.count
         return _dev.wrap(mean) if isinstance(mean, torch.Tensor) else mean
+
+    def result_float(self) -> float:
+        """``result()`` as a Python float (one device synchronisation when the mean lives on the device)."""
+        return float(self.result())
+
+
+def to_floats(logs):
+    """The dict a ``train_step`` / ``test_step`` returns (0-dim device tensors) as plain Python floats: ONE device-to-host copy
+    for all entries.  For logging / ``json.dumps``; the step functions themselves never synchronise."""
+    keys = list(logs)
+    dev = [k for k in keys if isinstance(logs[k], torch.Tensor)]
+    out = {k: float(logs[k]) for k in keys if k not in dev}
+    if dev:
+        vals = torch.stack([logs[k].detach().as_subclass(torch.Tensor).to(torch.float32).reshape(()) for k in dev]).cpu().tolist()
+        out.update(dict(zip(dev, vals)))
+    return {k: out[k] for k in keys}

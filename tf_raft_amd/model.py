@@ -41,6 +41,25 @@ from .layers.extractor import BasicEncoder, SmallEncoder
 from .layers.update import BasicUpdateBlock, SmallUpdateBlock, UpdateState
 
 
+
+def _rank_of_this_process() -> int:
+    """Data-parallel rank (0 without torch.distributed)."""
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _dropout_seed(model_seed: int, rank: int, step: int) -> int:
+    """Even 62-bit seed of a training step's two dropout masks (the second uses seed + 1): a splitmix64-style mix of the
+    model seed, the data-parallel rank and the step, so that ranks, models and steps draw independent masks."""
+    x = (int(model_seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xBF58476D1CE4E5B9 + int(step) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 31
+    return int(x >> 2) & ~1
+
+
 class RAFT:
     """reference model.py:10-109."""
 
@@ -58,6 +77,7 @@ class RAFT:
         self.corr_levels = 4
         self.corr_radius = 4
         self.drop_rate = drop_rate
+        self.seed = int(seed)                       # also mixed into the dropout mask seeds of train_step
         self.iters = iters
         self.iters_pred = iters_pred
         self.alternate_corr = alternate_corr
@@ -451,9 +471,14 @@ class RAFT:
             cnet, ctape = grad.encoder_forward(wts, 'cnet', x1, training=True)         # model.py:82
             cnet = cnet.as_subclass(torch.Tensor)
             if self.drop_rate:     # extractor.py:109-111, 127-128: Dropout on the encoder outputs while training
-                self._drop_step = getattr(self, '_drop_step', 0) + 1
-                fout, mf = grad.dropout_forward(fout, self.drop_rate, seed=2 * self._drop_step)
-                cnet, mc = grad.dropout_forward(cnet, self.drop_rate, seed=2 * self._drop_step + 1)
+                # mask seeds: a different stream per data-parallel rank (ranks see different shards), per model seed and per
+                # optimizer step -- optimizer.iterations is part of a checkpoint, so a resumed run continues the sequence
+                # instead of replaying the masks from step 1
+                step = int(getattr(getattr(self, 'optimizer', None), 'iterations', 0) or 0)
+                self._drop_step = max(getattr(self, '_drop_step', 0) + 1, step + 1)
+                base = _dropout_seed(getattr(self, 'seed', 0), _rank_of_this_process(), self._drop_step)
+                fout, mf = grad.dropout_forward(fout, self.drop_rate, seed=base)
+                cnet, mc = grad.dropout_forward(cnet, self.drop_rate, seed=base + 1)
                 drop_masks = [mf, mc]
             fmap1, fmap2 = fout[:B].contiguous(), fout[B:].contiguous()
         else:

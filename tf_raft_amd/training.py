@@ -103,5 +103,7 @@ class AdamW:
                                             arr([self._slots[k][1] for k in names]), sizes, n, lr_t, self.beta_1, self.beta_2,
                                             self.epsilon, wd, _dev.ptr(gn) if gn is not None else None,
                                             float(clip_norm) if clip_norm is not None else 0.0, _dev.stream_ptr()), 'adamw_step_multi')
+        from . import grad as _grad
+        _grad.bump_pack_version()      # the variables changed in place through raw pointers: packed copies of them are stale
         self.iterations += 1
         return gn

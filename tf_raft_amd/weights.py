@@ -188,12 +188,30 @@ CONDITIONED_HEAD = {'raft': (0.01, (0.02, 0.018)), 'small': (0.005, (0.02, 0.018
 MID_HEAD = {'raft': (0.2, (0.2, -0.15)), 'small': (0.1, (0.2, -0.15))}
 
 
-def condition_weights(variant: str, weights: Dict[str, np.ndarray], regime: str = 'conditioned') -> 'OrderedDict[str, np.ndarray]':
+# Jump regime (round 4): the conditioned regime plus an INTEGER drift per iteration.  The low-resolution flow after k
+# iterations is k * jump + c_k with c_k the conditioned regime's small trajectory (strictly inside (0, 1) per axis), so every
+# tap coordinate (x + flow) / 2^l + d keeps a fractional part >= ~0.01 / 2^l away from an integer -- no tap can sit within rounding
+# distance of the sampler's discontinuities (reference corr.py:41-60: exact integers and clamped coordinates sample 0) -- while
+# its integer part moves every iteration: lookup windows cross integers at every pyramid level, slide over the clamped borders
+# (|flow| reaches 24 .. 48 low-resolution pixels on a 56 x 64 map) and the coarse levels are sampled far from the identity.
+# tests/golden/make_conditioning.py records the oracle's fp32-vs-fp64 agreement AND the measured margin of every case.
+JUMP_HEAD = {'raft': (0.01, (0.02, 0.018)), 'small': (0.005, (0.02, 0.018))}
+JUMPS = ((1, -1), (-1, 1), (2, 1), (-1, -2), (1, 0), (0, -1), (-2, 2), (1, 1))
+
+
+def condition_weights(variant: str, weights: Dict[str, np.ndarray], regime: str = 'conditioned', jump=None) -> 'OrderedDict[str, np.ndarray]':
     """Copy of ``weights`` with ``update_block/flow_head/conv2`` scaled / biased per ``CONDITIONED_HEAD`` (regime
-    'conditioned') or ``MID_HEAD`` (regime 'mid')."""
-    if regime not in ('conditioned', 'mid'):
-        raise ValueError(f"regime must be 'conditioned' or 'mid', got {regime!r}")
-    scale, bias = (CONDITIONED_HEAD if regime == 'conditioned' else MID_HEAD)[variant]
+    'conditioned'), ``MID_HEAD`` (regime 'mid') or ``JUMP_HEAD`` + the integer drift ``jump`` = (jx, jy) low-resolution pixels per
+    iteration (regime 'jump'; 'jumpN' = entry N of ``JUMPS``)."""
+    if regime.startswith('jump'):
+        if jump is None:
+            jump = JUMPS[int(regime[4:] or 0) % len(JUMPS)]
+        scale, bias = JUMP_HEAD[variant]
+        bias = (bias[0] + int(jump[0]), bias[1] + int(jump[1]))
+    elif regime in ('conditioned', 'mid'):
+        scale, bias = (CONDITIONED_HEAD if regime == 'conditioned' else MID_HEAD)[variant]
+    else:
+        raise ValueError(f"regime must be 'conditioned', 'mid' or 'jump[N]', got {regime!r}")
     w = OrderedDict(weights)
     k = 'update_block/flow_head/conv2/'
     w[k + 'kernel'] = (weights[k + 'kernel'] * np.float32(scale)).astype(np.float32)

@@ -1,0 +1,49 @@
+#!/bin/bash
+# Closing set of a state of the tree (GPU box, repo root).  Everything bench.py's evidence fields point to is regenerated here
+# from the library that is loaded in the same call:
+#   <tag>_pytest_gpu.log, <tag>_smoke.log          the GPU suite and smoke()                      (skipped with SKIP_TESTS=1)
+#   <tag>_bench_b4.log                              the default bench line (BASELINE configs[1])
+#   <tag>_bench_b4_rocprofv3_kernel_stats.csv       rocprofv3 --kernel-trace --stats of the same command (product loop)
+#   <tag>_single_stream_b{4,8}_rocprofv3_kernel_stats.csv + kernel_durations.json   single-stream loop, per-stage durations
+#   <tag>_pmc_per_kernel.csv + pmc_traffic.json     FETCH_SIZE / WRITE_SIZE passes at 8 pairs      (skipped with SKIP_PMC=1)
+#   <tag>_loop_timeline_b4.txt                      kernel timeline of the product loop
+# usage: bash tools/closing_set.sh <tag>
+tag=${1:-r10a}
+export TMPDIR=/tmp
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out
+mkdir -p $out
+cd $root
+if [ -z "${SKIP_TESTS:-}" ]; then
+  timeout 1800 python -m pytest tests -m gpu -q -x > $out/${tag}_pytest_gpu.log 2>&1; echo "rc=$?" >> $out/${tag}_pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/${tag}_smoke.log 2>&1; echo "rc=$?" >> $out/${tag}_smoke.log
+fi
+cd /tmp
+for b in 4 8; do
+  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/${tag}_ss_b$b -o ss -- python $root/tools/pmc_loop.py $b 24 > $out/${tag}_ss_b$b.log 2>&1
+  f=$(ls $out/${tag}_ss_b$b/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_single_stream_b${b}_rocprofv3_kernel_stats.csv
+done
+t4=$(ls $out/${tag}_ss_b4/*kernel_trace.csv 2>/dev/null | head -1); t8=$(ls $out/${tag}_ss_b8/*kernel_trace.csv 2>/dev/null | head -1)
+cd $root
+[ -n "$t4" ] && [ -n "$t8" ] && python tools/kernel_durations.py $out/${tag}_kernel_durations.json 4=$t4 8=$t8 > $out/${tag}_kernel_durations.txt 2>&1
+rm -rf $out/${tag}_ss_b4 $out/${tag}_ss_b8
+if [ -z "${SKIP_PMC:-}" ]; then
+  bash tools/pmc_traffic.sh $tag 8 > $out/${tag}_pmc_traffic.txt 2>&1
+  rm -rf $out/${tag}_pmc
+fi
+# the bench line reads the two summaries just made (the same library is loaded: not stale)
+[ -f $out/${tag}_kernel_durations.json ] && cp $out/${tag}_kernel_durations.json profiles/kernel_durations.json
+[ -f $out/${tag}_pmc_traffic.json ] && cp $out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
+timeout 600 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_b4.log 2>&1
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $out/${tag}_prof -o bench -- python $root/bench.py --no-cpu-baseline --no-parity --steps 5 --warmup 2 > $out/${tag}_bench_b4_under_rocprof.log 2>&1
+f=$(ls $out/${tag}_prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_bench_b4_rocprofv3_kernel_stats.csv
+rm -rf $out/${tag}_prof
+timeout 200 rocprofv3 --kernel-trace -f csv -d $out/${tag}_tl -o tl -- python $root/tools/graph_probe.py 4 3 > $out/${tag}_tl.log 2>&1
+t=$(ls $out/${tag}_tl/*kernel_trace.csv 2>/dev/null | head -1)
+if [ -n "$t" ]; then python $root/tools/graph_trace.py $t "B=4 $tag" > $out/${tag}_loop_timeline_b4.txt 2>&1; python $root/tools/step_timeline.py $t all | awk 'NR>=72 && NR<=104' >> $out/${tag}_loop_timeline_b4.txt; fi
+rm -rf $out/${tag}_tl
+cd $root
+[ -z "${SKIP_TESTS:-}" ] && tail -3 $out/${tag}_pytest_gpu.log && tail -2 $out/${tag}_smoke.log
+tail -1 $out/${tag}_bench_b4.log | cut -c1-1500
+cat $out/${tag}_kernel_durations.txt 2>/dev/null | head -40

@@ -30,7 +30,22 @@ def algorithmic_bytes_per_pair(h=56, w=64):
         'fh1_mask0': M * (128 + 512) * f, 'fh2': M * (256 + 6) * f, 'mask2': M * (256 + 576) * f,
         'corr_build': 2 * M * 256 * f + sum((h >> l) * (w >> l) for l in range(4)) * M * f,
         'lookup_convc1_fused': M * (4 * 100 * f + 8 + 256 * f),      # footprints + coords in, cor1 out
+        'mask_upsample_fused': M * (256 * f + 8 + 64 * 2 * f),       # mask.0's output + flow in, 8x8x2 flow out (the mask is never stored)
     }
+
+
+def meta(raw_files):
+    """Where and on what the numbers were taken: digest of the HIP sources + flags of the library that ran (bench.py compares it
+    with its own and flags the file as stale otherwise), the commit, the raw files the summary was made from."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from tf_raft_amd import build
+    try:
+        head = subprocess.run(['git', '-C', root, 'rev-parse', '--short=12', 'HEAD'], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = ''
+    return {'source_digest': build.source_digest(), 'git_head': head or os.environ.get('RAFT_GIT_HEAD', ''), 'raw_files': raw_files}
 
 
 def read(root, counter):
@@ -57,6 +72,8 @@ def attribute(rows):
             out['corr_build_fmap_pyramid'].append(v)
         elif 'lookup_convc1' in name:
             out['lookup_convc1_fused'].append(v)
+        elif 'mask_upsample' in name:
+            out['mask_upsample_fused'].append(v)
     loop = rows[first:]
     last = max(i for i, r in enumerate(loop) if 'upsample_convex' in r[1])     # torch reductions of the caller follow
     loop = loop[:last + 1]
@@ -81,14 +98,15 @@ def main():
                        'single-stream loop, every kernel measured IN the loop; counters in KiB). hbm_bytes_per_launch = '
                        '2 * FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md HBM: gfx950 tallies 128-byte read requests at '
                        '64 bytes). Regenerate with: bash tools/pmc_traffic.sh <tag> 8'}
+    res['_meta'] = meta([os.path.basename(sys.argv[4])] if len(sys.argv) > 4 else [])
     rows = []
-    for st in STAGES + ['lookup_convc1_fused', 'corr_build', 'corr_build_fmap_pyramid']:
+    for st in STAGES + ['lookup_convc1_fused', 'mask_upsample_fused', 'corr_build', 'corr_build_fmap_pyramid']:
         if st not in fetch or st not in write:
             continue
         f = sum(fetch[st]) / len(fetch[st])
         wv = sum(write[st]) / len(write[st])
         hbm = (2 * f + wv) * 1024
-        res[st] = {'batch': batch, 'in_loop': st in STAGES or st == 'lookup_convc1_fused', 'fetch_size_kib_raw': round(f, 1), 'write_size_kib': round(wv, 1),
+        res[st] = {'batch': batch, 'in_loop': st in STAGES or st in ('lookup_convc1_fused', 'mask_upsample_fused'), 'fetch_size_kib_raw': round(f, 1), 'write_size_kib': round(wv, 1),
                    'hbm_bytes_per_launch': int(round(hbm)), 'launches_averaged': len(fetch[st]),
                    'algorithmic_bytes_per_pair': alg.get(st),
                    'algorithmic_bytes_per_launch': alg[st] * batch if st in alg else None,
