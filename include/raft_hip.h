@@ -54,6 +54,8 @@
  *   RAFT_CONVC2_KS      1/2  convc2 on the F(4x4) kernel in the loops: 8-row workgroups / K-split 4-row workgroups   (default: by grid size)
  *   RAFT_CONVF2_KS      1/2  the same for convf2                             (default: K-split below 56 eight-row workgroups)
  *   RAFT_GRU_Q_TNW      1/2  32- / 64-channel workgroups of the F(4,5) candidate-state convolutions            (default: by grid size)
+ *   RAFT_EVENT_FENCE    0/1  cross-stream events of a raft_loop_ctx without / with the system-scope fence of a default HIP event
+ *                            (read when the context is created)                                    (default 1)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)

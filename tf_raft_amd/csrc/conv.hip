@@ -894,7 +894,10 @@ extern "C" int raft_loop_ctx_create(raft_loop_ctx **out) {
     if (!c) return (int)hipErrorOutOfMemory;
     int rc = (int)hipGetDevice(&c->device);
     int made = 0;
-    for (; made < 4 && rc == RAFT_OK; ++made) rc = (int)hipEventCreateWithFlags(&c->ev[made], hipEventDisableTiming);
+    // The events order streams of ONE device: RAFT_EVENT_FENCE=0 creates them without the system-scope release / acquire a
+    // default event performs when it completes (hipEventDisableSystemFence) -- read once, when the context is created.
+    const unsigned flags = hipEventDisableTiming | (raft_opt(RAFT_OPT_EVENT_FENCE, 1) ? 0u : (unsigned)hipEventDisableSystemFence);
+    for (; made < 4 && rc == RAFT_OK; ++made) rc = (int)hipEventCreateWithFlags(&c->ev[made], flags);
     if (rc != RAFT_OK) {
         for (int k = 0; k < made - 1; ++k) (void)hipEventDestroy(c->ev[k]);
         free(c);
