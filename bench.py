@@ -506,27 +506,31 @@ def main():
 
     # ---------------- the same step in every weight regime: throughput must not depend on the weights (no data-dependent work
     # is skipped when the flow runs off the map), and element 0's 24 predictions are kept for the EPE half of the metric
-    regime_weights, regime_pred0, regime_rate = {}, {}, {}
+    regime_weights, regime_pred0, regime_rate, regime_rounds = {}, {}, {}, {}
     if world == 1 and not args.no_parity:
+        models = {}
         for reg in REGIMES:
-            w_r = wts if reg == 'default' else wm.condition_weights('raft', wts, reg)
-            m_r = model if reg == 'default' else tf_raft_amd.RAFT(iters_pred=ITERS, weights=w_r)
-            if reg == 'default':
-                rate = value
-            else:
-                for _ in range(max(1, args.warmup)):
-                    m_r([img1, img2], training=False)
+            regime_weights[reg] = wts if reg == 'default' else wm.condition_weights('raft', wts, reg)
+            models[reg] = model if reg == 'default' else tf_raft_amd.RAFT(iters_pred=ITERS, weights=regime_weights[reg])
+            for _ in range(max(1, args.warmup)):
+                models[reg]([img1, img2], training=False)
+        torch.cuda.synchronize()
+        rounds = 3                      # interleaved: box drift and allocator effects hit every regime alike; median per regime
+        for _ in range(rounds):
+            for reg in REGIMES:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(args.steps):
-                    m_r([img1, img2], training=False)
+                    models[reg]([img1, img2], training=False)
                 torch.cuda.synchronize()
-                rate = B * args.steps / (time.perf_counter() - t0)
-            preds = m_r([img1, img2], training=False)
+                regime_rounds.setdefault(reg, []).append(B * args.steps / (time.perf_counter() - t0))
+        for reg in REGIMES:
+            regime_rate[reg] = round(float(np.median(regime_rounds[reg])), 3)
+            preds = models[reg]([img1, img2], training=False)
             torch.cuda.synchronize()
             regime_pred0[reg] = [p_.as_subclass(torch.Tensor)[:1].cpu().numpy() for p_ in preds]
-            regime_weights[reg], regime_rate[reg] = w_r, round(rate, 3)
-            del preds, m_r
+            del preds
+        del models
 
     result = {
         'metric': METRIC, 'value': round(value, 3), 'unit': 'image-pairs/s',
@@ -756,44 +760,54 @@ def main():
                     'mask_bytes_not_moved': 8.0 * B * h * w * 576},
             'note': 'timed as a FULL launch in the single-stream replay; in the three-stream loop every iteration but the last runs it as '
                     '32 long-lived background workgroups on the CUs the chain leaves idle (DESIGN 4.6)'}
-        # The same stand-alone kernel in the single-stream loop at 8 pairs (BASELINE configs[2] per GPU): a 550 MB volume,
-        # larger than the 256 MiB Infinity Cache, which the 275 MB volume of 4 pairs is not (SURVEY 8d asks for B >= 8).
-        if world == 1 and B != 8:
-            i8a = torch.cat([img1, img1.flip(0)])[:8] if B >= 4 else img1[:1].expand(8, -1, -1, -1).contiguous()
-            i8b = torch.cat([img2, img2.flip(0)])[:8] if B >= 4 else img2[:1].expand(8, -1, -1, -1).contiguous()
-            f1, f2 = model.fnet([2 * (i8a / 255.0) - 1.0, 2 * (i8b / 255.0) - 1.0])
-            cn8 = model.cnet(2 * (i8a / 255.0) - 1.0)
-            corr8 = CorrBlock(f1, f2, num_levels=4, radius=4)
-            st8 = model._get_state(8, h, w, device)
-            up8 = torch.empty((ITERS, 8, H, W, 2), device=device)
+        # The same stand-alone kernel in the single-stream loop at 8 pairs (BASELINE configs[2] per GPU: a 550 MB volume, larger
+        # than the 256 MiB Infinity Cache, which the 275 MB volume of 4 pairs is not -- SURVEY 8d asks for B >= 8) and at 16 pairs
+        # (1.1 GB; the launch ramp of a 2.5 us empty grid is amortised over twice the bytes).
+        def lookup_at(nb):
+            rep = (nb + B - 1) // B
+            ia = torch.cat([img1, img1.flip(0)] * rep)[:nb] if B >= 2 else img1[:1].expand(nb, -1, -1, -1).contiguous()
+            ib = torch.cat([img2, img2.flip(0)] * rep)[:nb] if B >= 2 else img2[:1].expand(nb, -1, -1, -1).contiguous()
+            f1, f2 = model.fnet([2 * (ia / 255.0) - 1.0, 2 * (ib / 255.0) - 1.0])
+            cn = model.cnet(2 * (ia / 255.0) - 1.0)
+            corr_n = CorrBlock(f1, f2, num_levels=4, radius=4)
+            st_n = model._get_state(nb, h, w, device)
+            up_n = torch.empty((ITERS, nb, H, W, 2), device=device)
             _ffi.set_option('RAFT_LOOKUP_FUSED', 0)
             _ffi.set_option('RAFT_MASK_FUSED', 0)
             buf = (C.c_float * len(STAGES))()
-            acc8 = np.zeros(len(STAGES))
+            acc_n = np.zeros(len(STAGES))
             for _ in range(2):
-                model._prepare(cn8, st8)
+                model._prepare(cn, st_n)
                 _ffi.check(_dev.lib().raft_iterate_basic_timed_f32(
-                    C.byref(model.update_block.c), _dev.ptr(corr8._pyr), corr8._off, 8, h, w, ITERS, C.byref(st8.c),
-                    _dev.ptr(up8), _dev.stream_ptr(), buf), 'iterate_basic_timed')
-                acc8 += np.array(list(buf))
+                    C.byref(model.update_block.c), _dev.ptr(corr_n._pyr), corr_n._off, nb, h, w, ITERS, C.byref(st_n.c),
+                    _dev.ptr(up_n), _dev.stream_ptr(), buf), 'iterate_basic_timed')
+                acc_n += np.array(list(buf))
             _ffi.set_option('RAFT_LOOKUP_FUSED', None)
             _ffi.set_option('RAFT_MASK_FUSED', None)
-            l8_ms = max(float(acc8[0]) / (2 * ITERS) - bracket_ms, 1e-6)
-            b8 = stage_work(8, h, w)[1]['corr_lookup']
-            tr8, _ = pmc_traffic('corr_lookup', 8)
-            lk['at_8_pairs'] = {'ms_per_launch': round(l8_ms, 5), 'ms_per_launch_between_events': round(float(acc8[0]) / (2 * ITERS), 5),
-                                'bytes_per_launch': b8, 'achieved': round(b8 / (l8_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
-                                'frac': round(b8 / (l8_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                'frac_of_measured_copy': round(b8 / (l8_ms * 1e-3) / 1e9 / copy_gbs, 4), 'traffic': tr8}
-            del i8a, i8b, f1, f2, cn8, corr8, st8, up8
-        best = max(lk['frac_of_measured_copy'], lk.get('at_8_pairs', {}).get('frac_of_measured_copy', 0.0))
+            ln_ms = max(float(acc_n[0]) / (2 * ITERS) - bracket_ms, 1e-6)
+            bn = stage_work(nb, h, w)[1]['corr_lookup']
+            trn, _ = pmc_traffic('corr_lookup', nb)
+            return {'ms_per_launch': round(ln_ms, 5), 'ms_per_launch_between_events': round(float(acc_n[0]) / (2 * ITERS), 5),
+                    'bytes_per_launch': bn, 'achieved': round(bn / (ln_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
+                    'frac': round(bn / (ln_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                    'frac_of_measured_copy': round(bn / (ln_ms * 1e-3) / 1e9 / copy_gbs, 4), 'traffic': trn}
+        if world == 1 and B != 8:
+            lk['at_8_pairs'] = lookup_at(8)
+        if world == 1 and B != 16:
+            lk['at_16_pairs'] = lookup_at(16)
+            model._state = None                     # drop the 16-pair state buffers
+            torch.cuda.empty_cache()
+        best = max(lk['frac_of_measured_copy'], lk.get('at_8_pairs', {}).get('frac_of_measured_copy', 0.0),
+                   lk.get('at_16_pairs', {}).get('frac_of_measured_copy', 0.0))
         lk['target'] = {
             'north_star': '>= 0.60 of the measured HBM copy rate on algorithmic bytes, by kernel duration', 'best_frac_of_measured_copy': best,
             'target_met': bool(best >= 0.60),
-            'floor': 'PMC traffic is 1.32x the algorithmic bytes (a 10x10 footprint touches 6.9 128-byte tiles of a 4x8-tiled map, '
-                     '3.1 tiles of useful floats): at the copy rate the moved bytes alone are 0.76 of the time budget of the target, an '
-                     'empty launch of this grid 2.5 us more -- at 4 pairs floor 11.4 us against a target of 11.2 us (DESIGN.md section 5); '
-                     'in the product loop the kernel runs fused into convc1 and does not write its 18.6 MB output'}
+            'by_batch': {k: lk[k]['frac_of_measured_copy'] for k in ('at_8_pairs', 'at_16_pairs') if k in lk},
+            'floor': 'PMC traffic is 1.32x the algorithmic bytes: a 10x10 footprint touches 6.9 128-byte lines of a 4x8-tiled map (3.1 '
+                     'lines of useful floats), and the tile-shape study (profiles/r10b_lookup_layouts_*.txt: 8x4, 2x16, 4x4, 8x8, 2x8, '
+                     'row-major; FETCH_SIZE / TCC_EA0_RDREQ per shape) shows the fetch granule is the 128-byte line and no shape pulls '
+                     'fewer lines; a 2.5 us empty launch is the rest of the gap at small batches (DESIGN.md section 5); in the product '
+                     'loop the kernel runs fused into convc1 and does not write its 18.6 MB (4 pairs) output'}
         # corr_build = pooled-fmap2 pyramid (2 small launches) + ONE fp32-MFMA NT GEMM fmap1 . pyramid^T whose epilogue
         # writes all 4 levels.  Its floor is the GEMM (real FLOPs: every stored correlation value is a C-long dot
         # product), the HBM write of the volume sits below it -- both are reported, bound = "mfma".
@@ -829,10 +843,12 @@ def main():
             attach(result['roofline_' + name], name, bytes_[name], PEAK_HBM_GBS, 1e9)
             if result['roofline_' + name]['rocprof']:
                 result['roofline_' + name]['rocprof']['frac_of_measured_copy'] = round(result['roofline_' + name]['rocprof']['achieved'] / copy_gbs, 4)
-        if 'at_8_pairs' in lk:
-            attach(lk['at_8_pairs'], 'corr_lookup', lk['at_8_pairs']['bytes_per_launch'], PEAK_HBM_GBS, 1e9, batch=8)
-            if lk['at_8_pairs']['rocprof']:
-                lk['at_8_pairs']['rocprof']['frac_of_measured_copy'] = round(lk['at_8_pairs']['rocprof']['achieved'] / copy_gbs, 4)
+        for nb in (8, 16):
+            key = f'at_{nb}_pairs'
+            if key in lk:
+                attach(lk[key], 'corr_lookup', lk[key]['bytes_per_launch'], PEAK_HBM_GBS, 1e9, batch=nb)
+                if lk[key]['rocprof']:
+                    lk[key]['rocprof']['frac_of_measured_copy'] = round(lk[key]['rocprof']['achieved'] / copy_gbs, 4)
         attach(result['roofline_lookup_convc1_fused'], 'lookup_convc1_fused', lc_flops, PEAK_FP32_MFMA_TFLOPS, 1e12)
         attach(result['roofline_mask_upsample_fused'], 'mask_upsample_fused', flops['mask2'], PEAK_FP32_MFMA_TFLOPS, 1e12)
         attach(result['roofline_corr_build'], 'corr_build', build_flops, PEAK_FP32_MFMA_TFLOPS, 1e12)
@@ -915,6 +931,10 @@ def main():
             result['pairs_per_s_by_regime'] = regime_rate
             lo, hi = min(regime_rate.values()), max(regime_rate.values())
             result['regime_spread_frac'] = round((hi - lo) / hi, 4)
+            result['pairs_per_s_by_regime_rounds'] = {r: [round(v, 1) for v in vs] for r, vs in regime_rounds.items()}
+            result['regime_timing'] = (f'{len(next(iter(regime_rounds.values())))} interleaved rounds of {args.steps} steps per regime in this '
+                                       'process (same inputs, same launches; only the weights differ), median per regime; `value` is the '
+                                       'separately timed headline on the default weights')
         front = ['metric', 'value', 'unit', 'final_iter_epe', 'final_iter_epe_regimes', 'final_iter_epe_within_tolerance',
                  'final_iter_epe_by_regime', 'pairs_per_s_by_regime', 'regime_spread_frac']
         result = {**{k: result[k] for k in front if k in result}, **{k: v for k, v in result.items() if k not in front}}

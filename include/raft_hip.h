@@ -56,6 +56,8 @@
  *   RAFT_GRU_Q_TNW      1/2  32- / 64-channel workgroups of the F(4,5) candidate-state convolutions            (default: by grid size)
  *   RAFT_EVENT_FENCE    0/1  cross-stream events of a raft_loop_ctx without / with the system-scope fence of a default HIP event
  *                            (read when the context is created)                                    (default 1)
+ *   RAFT_CORR_XCD       0/1  volume build: plain (n, m, batch) tile grid / one region of the tile plane per XCD           (default 1)
+ *   RAFT_CORR_NT        0/1  volume build: epilogue stores plain / with the non-temporal hint                              (default 0)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)

@@ -97,6 +97,21 @@ def test_corr_build_matches_oracle_pyramid(rng, shape):
         assert err <= max(4 * err_ref, 2e-5)
 
 
+@pytest.mark.parametrize('shape', [(2, 56, 64, 256), (1, 44, 60, 64), (3, 128, 128, 32)])
+def test_corr_build_xcd_tile_order_is_bitwise_the_plain_grid(rng, shape, raft_opt):
+    """The XCD-aware workgroup -> tile mapping of the volume build (one region of the tile plane per XCD; default) covers every
+    tile exactly once: the whole pyramid, padding included, is bit for bit what the plain (n, m, batch) grid writes -- at the
+    benchmarked map size, a ragged one (partial edge tiles, unequal regions) and a 128 x 128 map (config 4)."""
+    from tf_raft_amd.layers.corr import CorrBlock
+    f1 = rng.normal(size=shape).astype(np.float32)
+    f2 = rng.normal(size=shape).astype(np.float32)
+    raft_opt.set('RAFT_CORR_XCD', '0')
+    plain = CorrBlock(f1, f2, num_levels=4, radius=4)._pyr.clone()
+    raft_opt.set('RAFT_CORR_XCD', '1')
+    xcd = CorrBlock(f1, f2, num_levels=4, radius=4)._pyr
+    assert torch.equal(plain, xcd)
+
+
 def _device_corr_with_oracle_pyramid(f1, f2, levels, radius):
     """Device CorrBlock whose volume is overwritten with the oracle's values, so the lookup can be
     compared in isolation (bit-exact arithmetic expected)."""

@@ -67,6 +67,24 @@ def stream_ptr() -> int:
         return torch.cuda.current_stream().cuda_stream
 
 
+# Side streams of the forward pass, ONE set per device and process, shared by every model object.  HIP maps streams onto a few
+# hardware queues in creation order (4 by default); a second model with streams of its own put its flow branch on the main
+# chain's queue and the two serialised (measured in round 4: the fifth RAFT object of a process ran at 211 instead of 324
+# pairs/s).  Work enqueued by different models is still ordered per model by events / wait_stream; two host threads driving two
+# models on one device share the side streams and interleave there.
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, role: str) -> 'torch.cuda.Stream':
+    """The process-wide side stream of ``role`` ('flow', 'mask', 'encoder', 'loop') on ``device``."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def i64_array(values):
     return (C.c_int64 * len(values))(*values)
 

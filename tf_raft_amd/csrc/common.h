@@ -36,12 +36,29 @@ static inline int raft_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1)
 // floats = one 128-byte line each, tiles row-major, maps padded to whole tiles.  The (2r+2)^2 lookup footprint
 // then touches ~6.9 lines of a large map instead of ~12.8 with row-major rows (the lookup is
 // bound by the lines it pulls from HBM, not by the 40 useful bytes per footprint row).
-constexpr int RAFT_TILE_H = 4, RAFT_TILE_W = 8, RAFT_TILE_FLOATS = 32;
+// The tile shape is a compile-time constant of the library (2^RAFT_TILE_H_LOG2 x 2^RAFT_TILE_W_LOG2; the product path and its
+// Python un-tiling use 4 x 8): tools/ablate/lookup_layout.sh rebuilds the volume build + lookup with other shapes (8 x 4,
+// 2 x 16, 4 x 4, 8 x 8, row-major 1 x 8) to measure the lines each pulls (profiles/r10*_lookup_layouts.txt).
+#ifndef RAFT_TILE_H_LOG2
+#define RAFT_TILE_H_LOG2 2
+#endif
+#ifndef RAFT_TILE_W_LOG2
+#define RAFT_TILE_W_LOG2 3
+#endif
+constexpr int RAFT_TILE_H = 1 << RAFT_TILE_H_LOG2, RAFT_TILE_W = 1 << RAFT_TILE_W_LOG2, RAFT_TILE_FLOATS = RAFT_TILE_H * RAFT_TILE_W;
 __host__ __device__ inline int raft_tiles_x(int w) { return (w + RAFT_TILE_W - 1) / RAFT_TILE_W; }
 __host__ __device__ inline int raft_tiles_y(int h) { return (h + RAFT_TILE_H - 1) / RAFT_TILE_H; }
-__host__ __device__ inline int raft_map_floats(int h, int w) { return raft_tiles_y(h) * raft_tiles_x(w) * RAFT_TILE_FLOATS; }
+// whole tiles, and whole 128-byte lines (32 floats) for tiles smaller than a line: every map starts on a line
+__host__ __device__ inline int raft_map_floats(int h, int w) { return (raft_tiles_y(h) * raft_tiles_x(w) * RAFT_TILE_FLOATS + 31) & ~31; }
 __host__ __device__ inline int raft_tiled_index(int y, int x, int tiles_x) {
-    return (((y >> 2) * tiles_x + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
+    return (((y >> RAFT_TILE_H_LOG2) * tiles_x + (x >> RAFT_TILE_W_LOG2)) << (RAFT_TILE_H_LOG2 + RAFT_TILE_W_LOG2)) +
+           ((y & (RAFT_TILE_H - 1)) << RAFT_TILE_W_LOG2) + (x & (RAFT_TILE_W - 1));
+}
+// inverse: float n of a tiled map -> (y, x); positions in the padding of the last tiles (or beyond them) come out >= h / w
+__host__ __device__ inline void raft_untiled_yx(int n, int tiles_x, int *y, int *x) {
+    const int t = n >> (RAFT_TILE_H_LOG2 + RAFT_TILE_W_LOG2);
+    *y = (t / tiles_x) * RAFT_TILE_H + ((n >> RAFT_TILE_W_LOG2) & (RAFT_TILE_H - 1));
+    *x = (t % tiles_x) * RAFT_TILE_W + (n & (RAFT_TILE_W - 1));
 }
 
 // Tuning switches (include/raft_hip.h: raft_set_option).  Process-global, initialised ONCE from the environment when the
@@ -52,7 +69,7 @@ enum RaftOptionId {
     RAFT_OPT_WINO_CK, RAFT_OPT_WINO1D_TM, RAFT_OPT_CONV_DEEP, RAFT_OPT_LOOKUP_LDS_PAD, RAFT_OPT_LOOKUP_STAGED,
     RAFT_OPT_LOOKUP_KERNEL, RAFT_OPT_LOOKUP_FUSED, RAFT_OPT_ONDEMAND_BLOCK, RAFT_OPT_ENC_TILE, RAFT_OPT_ENC_WINO, RAFT_OPT_LOOP_GRAPH,
     RAFT_OPT_WINO_KS, RAFT_OPT_CONV_WINO4, RAFT_OPT_WINO4_KS, RAFT_OPT_MASK_FUSED, RAFT_OPT_ENC_WINO4, RAFT_OPT_LOOP_ROTATE, RAFT_OPT_MASK_BG_WGS, RAFT_OPT_CONVC2_KS, RAFT_OPT_CONVF2_KS, RAFT_OPT_GRU_Q_TNW,
-    RAFT_OPT_EVENT_FENCE,
+    RAFT_OPT_EVENT_FENCE, RAFT_OPT_CORR_XCD, RAFT_OPT_CORR_NT,
     RAFT_OPT_COUNT
 };
 int raft_opt(int id, int dflt);
@@ -76,7 +93,7 @@ static inline int raft_make_geom(int h, int w, int levels, const int64_t *level_
     int ch = h, cw = w;
     for (int l = 0; l < RAFT_MAX_LEVELS; ++l) {
         g->lh[l] = g->lw[l] = g->tx[l] = 1;
-        g->map[l] = RAFT_TILE_FLOATS;
+        g->map[l] = raft_map_floats(1, 1);
         g->off[l] = 0;
     }
     for (int l = 0; l < levels; ++l) {

@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) fmap_tile_level0_kernel(const f32x4 *__re
     int64_t r = i / c4;
     const int n = (int)(r % map);
     const int64_t b = r / map;
-    const int t = n >> 5, y = (t / tiles_x) * 4 + ((n >> 3) & 3), x = (t % tiles_x) * 8 + (n & 7);
+    int y, x;
+    raft_untiled_yx(n, tiles_x, &y, &x);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (y < h && x < w) v = src[((b * h + y) * (int64_t)w + x) * c4 + c];
     dst[(b * tot_rows_per_b + n) * c4 + c] = v;
@@ -82,7 +83,8 @@ __global__ void __launch_bounds__(256) fmap_pool_kernel(f32x4 *__restrict__ ws, 
     int64_t r = i / c4;
     const int n = (int)(r % dmap);
     const int64_t b = r / dmap;
-    const int t = n >> 5, y = (t / dtx) * 4 + ((n >> 3) & 3), x = (t % dtx) * 8 + (n & 7);
+    int y, x;
+    raft_untiled_yx(n, dtx, &y, &x);
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (y < dh && x < dw) {
         const f32x4 *s = ws + (b * tot_rows_per_b + src_off) * c4 + c;
@@ -148,6 +150,8 @@ struct CorrGemmArgs {
     int N, T, C;
     float sqrt_c, rcp_sqrt_c;
     int rcp_exact;   // sqrt(C) is a power of two
+    int xcd_rm, xcd_rn, xcd_maxreg, tiles_m, tiles_n;   // XCD-aware tile order (xcd_rm == 0: plain 3-D grid)
+    int nt_store;                                       // epilogue stores with the non-temporal hint
 };
 
 constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32, CG_LD = 36;
@@ -159,8 +163,28 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z;
-    const int m0 = blockIdx.y * CG_BM, n0 = blockIdx.x * CG_BN;
+    // Workgroup -> tile.  xcd_rm == 0: the plain (n tile, m tile, batch) grid.  Otherwise (1-D grid) XCD-aware: the hardware
+    // places workgroup i on XCD i % 8, and each XCD has an L2 of its own (4 MB) -- so XCD x owns one REGION of the (m tile, n tile)
+    // plane of every batch element (xcd_rm x xcd_rn = 8 regions: 7 x 19 tiles each at 448x512) and walks it n-fastest: the ~64
+    // workgroups an XCD holds at a time touch ~3.4 A panels and the region's 19 B panels (2.9 MB), and over a batch element an
+    // XCD reads A/4 + B/2 = 3.4 MB instead of (nearly) all of A and B.
+    int b, m0, n0;
+    if (p.xcd_rm == 0) {
+        b = blockIdx.z;
+        m0 = blockIdx.y * CG_BM;
+        n0 = blockIdx.x * CG_BN;
+    } else {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        b = idx / p.xcd_maxreg;
+        const int t = idx - b * p.xcd_maxreg;
+        const int rm = xcd / p.xcd_rn, rn = xcd - rm * p.xcd_rn;
+        const int tm_lo = rm * p.tiles_m / p.xcd_rm, tm_hi = (rm + 1) * p.tiles_m / p.xcd_rm;
+        const int tn_lo = rn * p.tiles_n / p.xcd_rn, tn_hi = (rn + 1) * p.tiles_n / p.xcd_rn;
+        const int nw = tn_hi - tn_lo;
+        if (nw <= 0 || t >= (tm_hi - tm_lo) * nw) return;      // workgroup-uniform: region smaller than the largest one
+        m0 = (tm_lo + t / nw) * CG_BM;
+        n0 = (tn_lo + t % nw) * CG_BN;
+    }
     const float *A = p.a + (int64_t)b * p.N * p.C;
     const float *Bm = p.bmat + (int64_t)b * p.T * p.C;
 
@@ -243,7 +267,14 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 // corr.py:161 divides by sqrt(C); for C a power of four (256, 64) the reciprocal is exact and the
                 // product is the same float without the division sequence
-                if (m < p.N) base[(int64_t)m * map] = p.rcp_exact ? acc[i][j][r] * p.rcp_sqrt_c : acc[i][j][r] / p.sqrt_c;
+                if (m < p.N) {
+                    const float val = p.rcp_exact ? acc[i][j][r] * p.rcp_sqrt_c : acc[i][j][r] / p.sqrt_c;
+                    // the volume is written once and read by later kernels: streaming stores keep the A / B panels in L2
+                    if (p.nt_store)
+                        __builtin_nontemporal_store(val, base + (int64_t)m * map);
+                    else
+                        base[(int64_t)m * map] = val;
+                }
             }
         }
     }
@@ -284,8 +315,27 @@ extern "C" int raft_corr_build_f32(const float *fmap1, const float *fmap2, int B
         int e = 0;
         a.rcp_exact = frexpf(a.sqrt_c, &e) == 0.5f;   // mantissa 0.5 <=> power of two: x / 2^k == x * 2^-k exactly
     }
-    dim3 grid(raft_ceil_div(a.T, CG_BN), raft_ceil_div(a.N, CG_BM), B);
-    corr_gemm_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    a.tiles_m = (int)raft_ceil_div(a.N, CG_BM);
+    a.tiles_n = (int)raft_ceil_div(a.T, CG_BN);
+    a.xcd_rm = a.xcd_rn = a.xcd_maxreg = 0;
+    a.nt_store = raft_opt(RAFT_OPT_CORR_NT, 0);
+    if (raft_opt(RAFT_OPT_CORR_XCD, 1) != 0 && a.tiles_m * a.tiles_n >= 64) {   // small maps: nothing to gain, plain grid
+        a.xcd_rm = a.tiles_m >= 4 ? 4 : (a.tiles_m >= 2 ? 2 : 1);
+        a.xcd_rn = 8 / a.xcd_rm;
+        int mx = 0;
+        for (int rm = 0; rm < a.xcd_rm; ++rm)
+            for (int rn = 0; rn < a.xcd_rn; ++rn) {
+                const int mh = (rm + 1) * a.tiles_m / a.xcd_rm - rm * a.tiles_m / a.xcd_rm;
+                const int nw = (rn + 1) * a.tiles_n / a.xcd_rn - rn * a.tiles_n / a.xcd_rn;
+                mx = mh * nw > mx ? mh * nw : mx;
+            }
+        a.xcd_maxreg = mx;
+        RAFT_REQUIRE((int64_t)8 * mx * B < ((int64_t)1 << 31), RAFT_E_UNSUPPORTED);
+        corr_gemm_kernel<<<dim3(8 * mx * B), 256, 0, (hipStream_t)stream>>>(a);
+    } else {
+        dim3 grid(a.tiles_n, a.tiles_m, B);
+        corr_gemm_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    }
     return raft_launch_status();
 }
 
@@ -409,14 +459,36 @@ __device__ __forceinline__ void strip_eval(const float *f, const int (*ty4)[4], 
         for (int b = 0; b < G::D; ++b) o[b] = wx0 + (float)b;
         return;
     }
+    // Consecutive y offsets share a footprint row: away from the clamped borders and from exact-integer coordinates the
+    // upper row of tap b + 1 IS the lower row of tap b (i0(b + 1) == i1(b)), so its two values are kept in registers and the
+    // LDS reads are skipped when that holds for every active lane of the wave (a scalar branch; otherwise the wave reads as
+    // before -- the same addresses, hence the same values: bit-identical either way).  20 instead of 36 footprint reads per
+    // strip in the common case.
+    float lo0 = 0.f, lo1 = 0.f;
+    int lo_off = -1;
 #pragma unroll
     for (int b = 0; b < G::D; ++b) {
         const int4 ty = *(const int4 *)ty4[b];
         const float wy0 = __int_as_float(ty.z), wy1 = __int_as_float(ty.w);
         const float c00 = wy0 * wx0, c01 = wy0 * wx1, c10 = wy1 * wx0, c11 = wy1 * wx1;
-        float t = c00 * *(const float *)(f0 + ty.x) + c01 * *(const float *)(f1 + ty.x);
-        t = t + c10 * *(const float *)(f0 + ty.y);
-        t = t + c11 * *(const float *)(f1 + ty.y);
+        float u0, u1;
+#ifdef RAFT_LOOKUP_NOREUSE      // tools/ablate A/B: always read both rows
+        if (false) {
+#else
+        if (b > 0 && __builtin_amdgcn_ballot_w64(ty.x != lo_off) == 0) {
+#endif
+            u0 = lo0;
+            u1 = lo1;
+        } else {
+            u0 = *(const float *)(f0 + ty.x);
+            u1 = *(const float *)(f1 + ty.x);
+        }
+        lo0 = *(const float *)(f0 + ty.y);
+        lo1 = *(const float *)(f1 + ty.y);
+        lo_off = ty.y;
+        float t = c00 * u0 + c01 * u1;
+        t = t + c10 * lo0;
+        t = t + c11 * lo1;
         o[b] = t;
     }
 }

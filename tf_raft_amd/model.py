@@ -180,7 +180,7 @@ class RAFT:
 
     def _aux_streams(self, dev):
         if self._aux is None or self._aux[0].device != dev:
-            self._aux = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            self._aux = (_dev.side_stream(dev, 'flow'), _dev.side_stream(dev, 'mask'))
         return self._aux
 
     @contextlib.contextmanager
@@ -193,7 +193,7 @@ class RAFT:
             yield
             return
         if self._loop_stream is None or self._loop_stream.device != dev:
-            self._loop_stream = torch.cuda.Stream(device=dev)
+            self._loop_stream = _dev.side_stream(dev, 'loop')
         self._loop_stream.wait_stream(cur)
         with torch.cuda.stream(self._loop_stream):
             yield
@@ -226,7 +226,7 @@ class RAFT:
             # flow branch and mask branch of every iteration on two side streams (events inside the library)
             dev = flow_up.device
             if self._aux is None or self._aux[0].device != dev:
-                self._aux = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+                self._aux = (_dev.side_stream(dev, 'flow'), _dev.side_stream(dev, 'mask'))
             with self._capturable_stream(dev):
                 check(_dev.lib().raft_iterate_basic_overlap_f32(
                     C.byref(self.update_block.c), _dev.ptr(corr._pyr), corr._off, st.B, st.h, st.w, iters, C.byref(st.c),
@@ -242,7 +242,7 @@ class RAFT:
             # the same three-stream C loop, lookups computed on demand from fmap1 and the pooled fmap2 pyramid
             dev = flow_up.device
             if self._aux is None or self._aux[0].device != dev:
-                self._aux = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+                self._aux = (_dev.side_stream(dev, 'flow'), _dev.side_stream(dev, 'mask'))
             with self._capturable_stream(dev):
                 check(_dev.lib().raft_iterate_basic_ondemand_f32(
                     C.byref(self.update_block.c), _dev.ptr(corr.fmap1), _dev.ptr(corr._f2pyr), corr.fmap1.shape[-1],
@@ -290,7 +290,7 @@ class RAFT:
             # next to them (its one-workgroup-per-CU layers fill the tails of the feature encoder's launches)
             cur = torch.cuda.current_stream(image1.device)
             if self._enc_stream is None or self._enc_stream.device != image1.device:
-                self._enc_stream = torch.cuda.Stream(device=image1.device)
+                self._enc_stream = _dev.side_stream(image1.device, 'encoder')
             st = self._get_state(B, H // 8, W // 8, image1.device)    # (allocated under the caller's stream, like its other users)
             self._enc_stream.wait_stream(cur)      # also orders this call's state preparation behind the previous call's loop
             with torch.cuda.stream(self._enc_stream):

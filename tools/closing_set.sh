@@ -19,14 +19,14 @@ if [ -z "${SKIP_TESTS:-}" ]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/${tag}_smoke.log 2>&1; echo "rc=$?" >> $out/${tag}_smoke.log
 fi
 cd /tmp
-for b in 4 8; do
+for b in 4 8 16; do
   timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/${tag}_ss_b$b -o ss -- python $root/tools/pmc_loop.py $b 24 > $out/${tag}_ss_b$b.log 2>&1
   f=$(ls $out/${tag}_ss_b$b/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_single_stream_b${b}_rocprofv3_kernel_stats.csv
 done
-t4=$(ls $out/${tag}_ss_b4/*kernel_trace.csv 2>/dev/null | head -1); t8=$(ls $out/${tag}_ss_b8/*kernel_trace.csv 2>/dev/null | head -1)
+t4=$(ls $out/${tag}_ss_b4/*kernel_trace.csv 2>/dev/null | head -1); t8=$(ls $out/${tag}_ss_b8/*kernel_trace.csv 2>/dev/null | head -1); t16=$(ls $out/${tag}_ss_b16/*kernel_trace.csv 2>/dev/null | head -1)
 cd $root
-[ -n "$t4" ] && [ -n "$t8" ] && python tools/kernel_durations.py $out/${tag}_kernel_durations.json 4=$t4 8=$t8 > $out/${tag}_kernel_durations.txt 2>&1
-rm -rf $out/${tag}_ss_b4 $out/${tag}_ss_b8
+[ -n "$t4" ] && [ -n "$t8" ] && python tools/kernel_durations.py $out/${tag}_kernel_durations.json 4=$t4 8=$t8 ${t16:+16=$t16} > $out/${tag}_kernel_durations.txt 2>&1
+rm -rf $out/${tag}_ss_b4 $out/${tag}_ss_b8 $out/${tag}_ss_b16
 if [ -z "${SKIP_PMC:-}" ]; then
   bash tools/pmc_traffic.sh $tag 8 > $out/${tag}_pmc_traffic.txt 2>&1
   rm -rf $out/${tag}_pmc

@@ -15,4 +15,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "$c rc=$?" >> "$out/$c.log"
 done
 cd "$root"
-python tools/pmc_traffic.py "$out" "$batch" gpurun_out/${tag}_pmc_traffic.json "profiles/${tag}_pmc_per_kernel.csv"
+python tools/pmc_traffic.py "$out" "$batch" gpurun_out/${tag}_pmc_traffic.json "gpurun_out/${tag}_pmc_per_kernel.csv"
