@@ -25,7 +25,7 @@
  * library is loaded and is changed afterwards only through raft_set_option -- the launch path reads
  * an atomic, it never calls getenv:
  *   RAFT_CONV_TILE      "<code>" or "<npad>:<taps>:<code>,...": tile of the direct convolution kernels
- *                       (0..5 legacy (tap, chunk)-stepped tiles; 100 + 10*TH + TN halo tiles, TH in {4,7,8})
+ *                       (100 + 10*TH + TN: TH x 16-pixel x 64*TN-channel halo tiles, TH in {4,7,8}, TN in {1,2})
  *   RAFT_CONV_DEEP      0/1  deep weight prefetch of the single-column-block halo tiles          (default 1)
  *   RAFT_CONV_WINO      bit mask {1 convc2, 2 convf2, 4 conv, 8 fh1_mask0}: layers on the F(2x2,3x3) kernel (13)
  *   RAFT_CONV_WINO4     the same mask (bit 2 = convf2) for the F(4x4,3x3) kernel, preferred where its bit is set and the 6x6-tap weights
@@ -55,9 +55,9 @@
  *   RAFT_CONVF2_KS      1/2  the same for convf2                             (default: K-split below 56 eight-row workgroups)
  *   RAFT_GRU_Q_TNW      1/2  32- / 64-channel workgroups of the F(4,5) candidate-state convolutions            (default: by grid size)
  *   RAFT_EVENT_FENCE    0/1  cross-stream events of a raft_loop_ctx without / with the system-scope fence of a default HIP event
- *                            (read when the context is created)                                    (default 1)
+ *                            (read when the context is created)                                    (default 0: the events
+ *                            only order streams of one device; +0.4 .. 0.9 %, profiles/r10c_event_fence.txt)
  *   RAFT_CORR_XCD       0/1  volume build: plain (n, m, batch) tile grid / one region of the tile plane per XCD           (default 1)
- *   RAFT_CORR_NT        0/1  volume build: epilogue stores plain / with the non-temporal hint                              (default 0)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)

@@ -340,7 +340,7 @@ def _conv_device(x_srcs, kernel, bias, act, scale=1.0, nvalid=None):
     return _np(out)
 
 
-@pytest.mark.parametrize('tile', ['0', '1', '2', '3', '4', '5', '141', '142', '171', '172', '181', '182'])   # conv.hip tile codes
+@pytest.mark.parametrize('tile', ['141', '142', '171', '172', '181', '182'])   # conv.hip tile codes
 @pytest.mark.parametrize('ksize', [(1, 1), (3, 3), (1, 5), (5, 1)])
 def test_conv2d_mfma_matches_oracle(rng, ksize, tile, raft_opt):
     from oracle import tf_ops
@@ -750,7 +750,7 @@ def test_small_update_block_matches_oracle(rng, shape):
 
 
 @pytest.mark.parametrize('variant', ['raft', 'small'])
-@pytest.mark.parametrize('tile', ['0', '1', '2', '3', '4', '5', '141', '142', '171', '172', '181', '182'])
+@pytest.mark.parametrize('tile', ['141', '142', '171', '172', '181', '182'])
 def test_update_blocks_every_conv_tile(rng, variant, tile, raft_opt):
     """GRU / relu / linear epilogues of every instantiated tile (forced through RAFT_CONV_TILE where the
     tile divides the layer's npad), M = 2*9*13 = 234 pixels: M tails of the 64/112/128-row tiles."""

@@ -23,51 +23,12 @@ static bool mask_is_fused(const raft_basic_update_weights *wts, int64_t pixels) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// tile selection + dispatch of the implicit-GEMM kernel
+// tile selection + dispatch of the direct (halo-tiled) convolution kernel
 // ------------------------------------------------------------------------------------------------
-struct TileInfo {
-    int mf, bm, bn;
-    int lds_bytes;
-};
-static const TileInfo kTiles[TILE_COUNT] = {
-    {32, 128, 128, 2 * (128 * 36 + 32 * 128) * 4}, {32, 64, 128, 2 * (64 * 36 + 32 * 128) * 4},
-    {32, 128, 64, 2 * (128 * 36 + 32 * 64) * 4},   {32, 64, 64, 2 * (64 * 36 + 32 * 64) * 4},
-    {16, 112, 128, 2 * (128 * 40 + 32 * 128) * 4}, {16, 112, 64, 2 * (128 * 40 + 32 * 64) * 4},
-};
-
-template <int KH, int KW, int EPI>
-static int launch_conv_tile(const ConvArgs &a, int tile, hipStream_t s) {
-    const int64_t M = (int64_t)a.B * a.H * a.W;
-    const TileInfo &t = kTiles[tile];
-    const int grid = raft_ceil_div(M, t.bm) * (a.npad / t.bn);
-    switch (tile) {
-        case TILE_32_128x128: conv_mfma_kernel<KH, KW, 32, 128, 128, 2, 2, EPI><<<grid, 256, 0, s>>>(a); break;
-        case TILE_32_64x128: conv_mfma_kernel<KH, KW, 32, 64, 128, 2, 2, EPI><<<grid, 256, 0, s>>>(a); break;
-        case TILE_32_128x64: conv_mfma_kernel<KH, KW, 32, 128, 64, 2, 2, EPI><<<grid, 256, 0, s>>>(a); break;
-        case TILE_32_64x64: conv_mfma_kernel<KH, KW, 32, 64, 64, 2, 2, EPI><<<grid, 256, 0, s>>>(a); break;
-        case TILE_16_112x128: conv_mfma_kernel<KH, KW, 16, 112, 128, 1, 4, EPI><<<grid, 256, 0, s>>>(a); break;
-        case TILE_16_112x64: conv_mfma_kernel<KH, KW, 16, 112, 64, 1, 4, EPI><<<grid, 256, 0, s>>>(a); break;
-        default: return RAFT_E_UNSUPPORTED;
-    }
-    return raft_launch_status();
-}
-
-template <int KH, int KW>
-static int launch_conv_epi(const ConvArgs &a, int epi, int tile, hipStream_t s) {
-    switch (epi) {
-        case EPI_LINEAR: return launch_conv_tile<KH, KW, EPI_LINEAR>(a, tile, s);
-        case EPI_RELU: return launch_conv_tile<KH, KW, EPI_RELU>(a, tile, s);
-        case EPI_GRU_ZR: return launch_conv_tile<KH, KW, EPI_GRU_ZR>(a, tile, s);
-        case EPI_GRU_Q: return launch_conv_tile<KH, KW, EPI_GRU_Q>(a, tile, s);
-    }
-    return RAFT_E_UNSUPPORTED;
-}
-
 // Tuning / test override: RAFT_CONV_TILE is either one code (applies to every convolution whose npad
 // it divides) or a comma-separated list of `npad:taps:code` entries, e.g. "256:5:171,128:5:141".
-// code 0..5 = legacy (tap, chunk)-stepped tiles (ConvTile); 100 + 10*TH + TN = halo-tiled kernel.
+// code = 100 + 10*TH + TN: TH x 16-pixel x 64*TN-channel workgroups of the halo-tiled kernel.
 static bool code_valid(int code, int npad) {
-    if (code >= 0 && code < TILE_COUNT) return npad % kTiles[code].bn == 0;
     if (code >= 100) {
         const int th = (code - 100) / 10, tn = (code - 100) % 10;
         return (th == 4 || th == 7 || th == 8) && (tn == 1 || tn == 2) && npad % (64 * tn) == 0;
@@ -82,7 +43,7 @@ static int forced_code(int npad, int taps) { return raft_opt_conv_tile(npad, tap
 // per SIMD exposes prologue / barrier / epilogue latency, three or more hide it.
 static int pick_code(const ConvArgs &a, int kh, int kw) {
     const int f = forced_code(a.npad, kh * kw);
-    if (f >= 100 || (f >= 0 && !a.init)) return f;   // the legacy tiles have no accumulator preload
+    if (f >= 100) return f;
     static const int ths[3] = {4, 7, 8};
     double best = 1e30;
     int best_code = 141;
@@ -143,10 +104,7 @@ int raft_launch_conv(const ConvArgs &a_in, int kh, int kw, int epi, hipStream_t 
         if (kh == 1 && kw == 5) return raft_launch_conv_halo_1x5(a, th, tn, epi, s);
         return raft_launch_conv_halo_5x1(a, th, tn, epi, s);
     }
-    if (kh == 1 && kw == 1) return launch_conv_epi<1, 1>(a, epi, code, s);
-    if (kh == 3 && kw == 3) return launch_conv_epi<3, 3>(a, epi, code, s);
-    if (kh == 1 && kw == 5) return launch_conv_epi<1, 5>(a, epi, code, s);
-    return launch_conv_epi<5, 1>(a, epi, code, s);
+    return RAFT_E_UNSUPPORTED;
 }
 
 extern "C" int raft_conv2d_f32(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
@@ -894,9 +852,13 @@ extern "C" int raft_loop_ctx_create(raft_loop_ctx **out) {
     if (!c) return (int)hipErrorOutOfMemory;
     int rc = (int)hipGetDevice(&c->device);
     int made = 0;
-    // The events order streams of ONE device: RAFT_EVENT_FENCE=0 creates them without the system-scope release / acquire a
-    // default event performs when it completes (hipEventDisableSystemFence) -- read once, when the context is created.
-    const unsigned flags = hipEventDisableTiming | (raft_opt(RAFT_OPT_EVENT_FENCE, 1) ? 0u : (unsigned)hipEventDisableSystemFence);
+    // The events order streams of ONE device, so they are created without the system-scope release / acquire that a default
+    // HIP event performs when it completes (hipEventDisableSystemFence): kernel boundaries still release / acquire at agent
+    // scope, which is what consecutive kernels of one stream rely on too; host and peer visibility of the results comes from
+    // the caller's stream synchronisation, not from these events.  329.8 against 326.3 - 327.0 pairs/s at 4 pairs, 358.8
+    // against 357.1 - 357.6 at 8 (A/B/A in one process, profiles/r10c_event_fence.txt); RAFT_EVENT_FENCE=1 restores the fence
+    // (read once, when the context is created).
+    const unsigned flags = hipEventDisableTiming | (raft_opt(RAFT_OPT_EVENT_FENCE, 0) ? 0u : (unsigned)hipEventDisableSystemFence);
     for (; made < 4 && rc == RAFT_OK; ++made) rc = (int)hipEventCreateWithFlags(&c->ev[made], flags);
     if (rc != RAFT_OK) {
         for (int k = 0; k < made - 1; ++k) (void)hipEventDestroy(c->ev[k]);

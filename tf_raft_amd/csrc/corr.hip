@@ -151,7 +151,6 @@ struct CorrGemmArgs {
     float sqrt_c, rcp_sqrt_c;
     int rcp_exact;   // sqrt(C) is a power of two
     int xcd_rm, xcd_rn, xcd_maxreg, tiles_m, tiles_n;   // XCD-aware tile order (xcd_rm == 0: plain 3-D grid)
-    int nt_store;                                       // epilogue stores with the non-temporal hint
 };
 
 constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32, CG_LD = 36;
@@ -269,11 +268,8 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
                 // product is the same float without the division sequence
                 if (m < p.N) {
                     const float val = p.rcp_exact ? acc[i][j][r] * p.rcp_sqrt_c : acc[i][j][r] / p.sqrt_c;
-                    // the volume is written once and read by later kernels: streaming stores keep the A / B panels in L2
-                    if (p.nt_store)
-                        __builtin_nontemporal_store(val, base + (int64_t)m * map);
-                    else
-                        base[(int64_t)m * map] = val;
+                    // (non-temporal stores measured no different in time or fabric reads: profiles/r10c_corr_build_ab.txt)
+                    base[(int64_t)m * map] = val;
                 }
             }
         }
@@ -318,7 +314,6 @@ extern "C" int raft_corr_build_f32(const float *fmap1, const float *fmap2, int B
     a.tiles_m = (int)raft_ceil_div(a.N, CG_BM);
     a.tiles_n = (int)raft_ceil_div(a.T, CG_BN);
     a.xcd_rm = a.xcd_rn = a.xcd_maxreg = 0;
-    a.nt_store = raft_opt(RAFT_OPT_CORR_NT, 0);
     if (raft_opt(RAFT_OPT_CORR_XCD, 1) != 0 && a.tiles_m * a.tiles_n >= 64) {   // small maps: nothing to gain, plain grid
         a.xcd_rm = a.tiles_m >= 4 ? 4 : (a.tiles_m >= 2 ? 2 : 1);
         a.xcd_rn = 8 / a.xcd_rm;
@@ -459,36 +454,18 @@ __device__ __forceinline__ void strip_eval(const float *f, const int (*ty4)[4], 
         for (int b = 0; b < G::D; ++b) o[b] = wx0 + (float)b;
         return;
     }
-    // Consecutive y offsets share a footprint row: away from the clamped borders and from exact-integer coordinates the
-    // upper row of tap b + 1 IS the lower row of tap b (i0(b + 1) == i1(b)), so its two values are kept in registers and the
-    // LDS reads are skipped when that holds for every active lane of the wave (a scalar branch; otherwise the wave reads as
-    // before -- the same addresses, hence the same values: bit-identical either way).  20 instead of 36 footprint reads per
-    // strip in the common case.
-    float lo0 = 0.f, lo1 = 0.f;
-    int lo_off = -1;
+    // (Round 4 tried keeping the lower row of tap b in registers for tap b + 1 -- i0(b + 1) == i1(b) away from borders and exact
+    // integers: 20 instead of 36 footprint reads per strip behind a wave-uniform ballot.  12.7 against 13.4 us at 4 pairs, but
+    // 23.5 - 23.9 against 22.7 us at 8 and 43.8 - 44.4 against 42.7 at 16, where the kernel is judged: the branch per tap keeps
+    // the compiler from issuing the strip's LDS reads as one batch.  profiles/r10c_lookup_row_reuse_ab.txt; not kept.)
 #pragma unroll
     for (int b = 0; b < G::D; ++b) {
         const int4 ty = *(const int4 *)ty4[b];
         const float wy0 = __int_as_float(ty.z), wy1 = __int_as_float(ty.w);
         const float c00 = wy0 * wx0, c01 = wy0 * wx1, c10 = wy1 * wx0, c11 = wy1 * wx1;
-        float u0, u1;
-#ifdef RAFT_LOOKUP_NOREUSE      // tools/ablate A/B: always read both rows
-        if (false) {
-#else
-        if (b > 0 && __builtin_amdgcn_ballot_w64(ty.x != lo_off) == 0) {
-#endif
-            u0 = lo0;
-            u1 = lo1;
-        } else {
-            u0 = *(const float *)(f0 + ty.x);
-            u1 = *(const float *)(f1 + ty.x);
-        }
-        lo0 = *(const float *)(f0 + ty.y);
-        lo1 = *(const float *)(f1 + ty.y);
-        lo_off = ty.y;
-        float t = c00 * u0 + c01 * u1;
-        t = t + c10 * lo0;
-        t = t + c11 * lo1;
+        float t = c00 * *(const float *)(f0 + ty.x) + c01 * *(const float *)(f1 + ty.x);
+        t = t + c10 * *(const float *)(f0 + ty.y);
+        t = t + c11 * *(const float *)(f1 + ty.y);
         o[b] = t;
     }
 }

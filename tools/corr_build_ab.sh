@@ -6,9 +6,9 @@ export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=${1:-$root/gpurun_out/corr_build_ab.txt}
 : > $out
-for x in 0 1 nt; do
+for x in 0 1; do
   for b in 4 8; do
-    if [ $x = nt ]; then export RAFT_CORR_NT=1; xx=1; else export RAFT_CORR_NT=0; xx=$x; fi
+    xx=$x
     d=/tmp/cb_${x}_$b; rm -rf $d; mkdir -p $d
     (cd /tmp && RAFT_CORR_XCD=$xx rocprofv3 --kernel-trace --stats -f csv -d $d/kt -o k -- python $root/tools/pmc_loop.py $b 2 > $d/kt.log 2>&1
      RAFT_CORR_XCD=$xx rocprofv3 --pmc FETCH_SIZE -f csv -d $d/f -o p -- python $root/tools/pmc_loop.py $b 2 > $d/f.log 2>&1
