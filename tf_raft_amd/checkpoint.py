@@ -15,7 +15,9 @@ published layouts (leveldb ``table_format.md``; tensorflow ``core/protobuf/tenso
 * table file = blocks, each followed by a 5-byte trailer (compression type, masked CRC-32C); footer
   (48 bytes) = metaindex handle, index handle (varint64 offset, size), zero padding to 40 bytes, magic
   ``0xdb4775248b80fb57``; a block = prefix-compressed entries ``varint32 shared | varint32 non_shared |
-  varint32 value_len | key delta | value`` + ``uint32 restarts[n] | uint32 n``;
+  varint32 value_len | key delta | value`` + ``uint32 restarts[n] | uint32 n``; compression type 0 = none (what
+  TensorFlow's BundleWriter asks for), 1 = snappy (raw block format, decoded by ``snappy_decompress`` -- pinned in the tests
+  to the format description's cases and to pyarrow's independent snappy codec);
 * ``BundleEntryProto``: 1 dtype, 2 shape (TensorShapeProto: repeated 2 dim {1 size}), 3 shard_id,
   4 offset, 5 size, 6 crc32c (fixed32, masked); ``BundleHeaderProto``: 1 num_shards, 2 endianness, 3 version.
 
@@ -28,8 +30,9 @@ combination is tried.  ``write_tensor_bundle`` produces files in the same format
 fixtures and lets weights travel back to TensorFlow tooling that reads bundles by name.
 
 **Parity status**: no TensorFlow-written checkpoint is available in this environment (no network, no TF), so
-the reader is pinned against the format documents and its own writer, not against a file produced by
-TensorFlow -- "parity unpinned" for real checkpoints.
+the reader is pinned against the format documents, a bundle assembled byte by byte in the tests, the RFC 3720 CRC-32C
+vectors, an independent snappy implementation and its own writer -- not against a file produced by TensorFlow: "parity
+unpinned" for real checkpoints.
 """
 from __future__ import annotations
 
@@ -211,10 +214,67 @@ def _read_block(buf: bytes, offset: int, size: int, verify: bool) -> bytes:
         want = struct.unpack_from('<I', buf, offset + size + 1)[0]
         if mask_crc(crc32c(buf[offset:offset + size + 1])) != want:
             raise CheckpointError(f'block at offset {offset}: CRC-32C mismatch')
+    if ctype == 1:                    # kSnappyCompression.  TensorFlow's BundleWriter asks for uncompressed index blocks
+        return snappy_decompress(data)   # (tensor_bundle.cc: options.compression = kNoCompression); other LevelDB writers do not
     if ctype != 0:
-        raise CheckpointError(f'block at offset {offset} is compressed (type {ctype}); TensorFlow writes bundle '
-                              'indices uncompressed -- snappy blocks are not supported')
+        raise CheckpointError(f'block at offset {offset} has unknown compression type {ctype} (0 = none, 1 = snappy)')
     return data
+
+
+def snappy_decompress(data: bytes) -> bytes:
+    """Raw snappy block format (what LevelDB tables store; format_description.txt of google/snappy): a varint with the
+    uncompressed length, then elements tagged by the low two bits of their first byte -- 00 literal (length - 1 in the upper six
+    bits, 60..63 = that many minus 59 little-endian length bytes follow), 01 copy with an 11-bit offset (length 4..11), 10 / 11
+    copy with a 2- / 4-byte little-endian offset (length 1..64).  Copies may overlap their own output (run-length)."""
+    try:
+        total, pos = _get_varint(data, 0)
+        out = bytearray()
+        n = len(data)
+        while pos < n:
+            tag = data[pos]
+            pos += 1
+            kind = tag & 3
+            if kind == 0:
+                ln = tag >> 2
+                if ln >= 60:
+                    nb = ln - 59
+                    if pos + nb > n:
+                        raise CheckpointError('snappy: truncated literal length')
+                    ln = int.from_bytes(data[pos:pos + nb], 'little')
+                    pos += nb
+                ln += 1
+                if pos + ln > n:
+                    raise CheckpointError('snappy: literal runs past the end of the block')
+                out += data[pos:pos + ln]
+                pos += ln
+                continue
+            if pos + (1, 2, 4)[kind - 1] > n:
+                raise CheckpointError('snappy: truncated copy element')
+            if kind == 1:
+                ln = 4 + ((tag >> 2) & 7)
+                off = ((tag >> 5) << 8) | data[pos]
+                pos += 1
+            elif kind == 2:
+                ln = (tag >> 2) + 1
+                off = int.from_bytes(data[pos:pos + 2], 'little')
+                pos += 2
+            else:
+                ln = (tag >> 2) + 1
+                off = int.from_bytes(data[pos:pos + 4], 'little')
+                pos += 4
+            if off == 0 or off > len(out):
+                raise CheckpointError('snappy: copy offset outside the data produced so far')
+            if off >= ln:
+                start = len(out) - off
+                out += out[start:start + ln]
+            else:                                   # overlapping copy: the pattern of the last `off` bytes repeats
+                for _ in range(ln):
+                    out.append(out[-off])
+        if len(out) != total:
+            raise CheckpointError(f'snappy: block decompresses to {len(out)} bytes, its header says {total}')
+        return bytes(out)
+    except IndexError as exc:
+        raise CheckpointError('snappy: truncated block') from exc
 
 
 def _block_entries(block: bytes) -> List[Tuple[bytes, bytes]]:
