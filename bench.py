@@ -691,7 +691,7 @@ def main():
                 roof['frac_algorithmic'] = round(alg / PEAK_FP32_MFMA_TFLOPS, 4)
             if ratio == 4.0 and dom in ('convc2', 'fh1_mask0', 'conv', 'convf2'):
                 # launch geometry of the F(4x4) kernel: at 448 x 512 the counts are 7 * 2^k -- a single round of workgroups that
-                # leaves CUs to the side branches of the three-stream loop, so the whole-chip fraction above
+                # leaves CUs to the side branches of the three-stream loop (docs/NOTEBOOK.md 4.5 / 4.6), so the whole-chip fraction above
                 # has the occupied-CU fraction beside it
                 wgs, ksplit = wino4_launch_shape(dom, B, h, w)
                 occ = min(1.0, wgs / 256.0)
@@ -759,7 +759,7 @@ def main():
             'hbm': {'algorithmic_bytes_per_launch': mu_bytes, 'gbs': round(mu_bytes / (mu_us * 1e-6) / 1e9, 1),
                     'mask_bytes_not_moved': 8.0 * B * h * w * 576},
             'note': 'timed as a FULL launch in the single-stream replay; in the three-stream loop every iteration but the last runs it as '
-                    '32 long-lived background workgroups on the CUs the chain leaves idle (DESIGN 4.6)'}
+                    '32 long-lived background workgroups on the CUs the chain leaves idle (docs/NOTEBOOK.md 4.6)'}
         # The same stand-alone kernel in the single-stream loop at 8 pairs (BASELINE configs[2] per GPU: a 550 MB volume, larger
         # than the 256 MiB Infinity Cache, which the 275 MB volume of 4 pairs is not -- SURVEY 8d asks for B >= 8) and at 16 pairs
         # (1.1 GB; the launch ramp of a 2.5 us empty grid is amortised over twice the bytes).

@@ -13,6 +13,14 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The CPU oracle is an eager torch graph of small ops: on the GPU boxes' 256 logical CPUs torch's default (128 threads) runs
+    # one (1,448,512,3) forward in 6 s, 16 threads in 0.65 s (bench.py probes the same: cpu_baseline.cores).  The parity tests
+    # run it dozens of times.
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1, torch.get_num_threads())))
+    except Exception:   # noqa: BLE001
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

@@ -60,7 +60,7 @@ def test_no_kernel_spills_and_the_occupancy_budgets_hold(tmp_path):
     # on-demand lookup: three workgroups per CU = 168 VGPRs and a third of the LDS (ondemand.hip)
     for n, v in pick(r'corr_lookup_ondemand_block_kernel').items():
         assert v['vgpr'] <= 168 and v['lds'] * 3 <= 160 * 1024, (n, v)
-    # volume lookup: eight workgroups per CU
+    # volume lookup: eight workgroups per CU (docs/NOTEBOOK.md 4.3)
     for n, v in pick(r'corr_lookup_strip_kernel').items():
         assert v['vgpr'] <= 64 and v['lds'] * 8 <= 160 * 1024, (n, v)
     # Winograd F(2x2,3x3): two 256-thread workgroups per CU (<= 256 VGPRs, <= 80 KB); the split-K variant one 512-thread one

@@ -40,7 +40,7 @@ static int forced_code(int npad, int taps) { return raft_opt_conv_tile(npad, tap
 // Pick the halo tile (TH x 16 pixels, 64*TN channels) by a small cost model of MI355X (256 CUs):
 //   time ~ (workgroups per CU, rounded up) x (MFMA work of one tile) x (latency-hiding penalty),
 // where the penalty reflects how many workgroups (= waves per SIMD) are co-resident on a CU: one wave
-// per SIMD exposes prologue / barrier / epilogue latency, three or more hide it.
+// per SIMD exposes prologue / barrier / epilogue latency, three or more hide it (docs/NOTEBOOK.md section 4.1).
 static int pick_code(const ConvArgs &a, int kh, int kw) {
     const int f = forced_code(a.npad, kh * kw);
     if (f >= 100) return f;
@@ -229,7 +229,7 @@ static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weig
 // The 3x3 layers of the update block run either on the direct halo kernel or on the Winograd F(2x2, 3x3) kernel
 // (conv_wino.h) when the caller supplied transformed weights.  RAFT_CONV_WINO is a bit mask over
 // {1: convc2, 2: convf2, 4: conv, 8: fh1_mask0}; unset = RAFT_WINO_DEFAULT (the layers where it measured faster at
-// B = 4).  Read per call so that tests can switch it.
+// B = 4, docs/NOTEBOOK.md section 4.4).  Read per call so that tests can switch it.
 constexpr int RAFT_WINO_DEFAULT = 13;
 constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr, 4: gru_q, 8: fh1}, switch RAFT_SMALL_WINO
 // F(4x4, 3x3) (conv_wino4.h), switch RAFT_CONV_WINO4 = bit mask {1: convc2, 4: conv, 8: fh1_mask0 / fh1}.  Default (us alone,
@@ -979,7 +979,7 @@ static void copy_weights_clean(raft_basic_update_weights *dst, const raft_basic_
 // and ~100 event operations from the host every call.  Default 0: measured on MI355X / ROCm 7.2 the replay is SLOWER
 // than the stream launches at every batch size (B = 1: 8.44 vs 7.94 ms, B = 4: 15.9 vs 15.4 ms,
 // profiles/r05a_batch_sweep.txt) -- the host is not the limiter of the small-batch loop, the dependent chain of short
-// kernels on the GPU is.  Kept as a switch: bit-identical results, one launch per forward.
+// kernels on the GPU is (docs/NOTEBOOK.md section 4.2).  Kept as a switch: bit-identical results, one launch per forward.
 static bool use_loop_graph(int, int, int) { return raft_opt(RAFT_OPT_LOOP_GRAPH, 0) != 0; }
 
 static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, const LookupSource &src, int B, int h, int w,
