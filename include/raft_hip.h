@@ -57,7 +57,8 @@
  *   RAFT_EVENT_FENCE    0/1  cross-stream events of a raft_loop_ctx without / with the system-scope fence of a default HIP event
  *                            (read when the context is created)                                    (default 0: the events
  *                            only order streams of one device; +0.4 .. 0.9 %, profiles/r10c_event_fence.txt)
- *   RAFT_CORR_XCD       0/1  volume build: plain (n, m, batch) tile grid / one region of the tile plane per XCD           (default 1)
+ *   RAFT_CORR_XCD       0/1/n  volume build: plain (n, m, batch) tile grid / one region of the tile plane per XCD, walked in strips
+ *                            of 2 (n >= 2: n) column tiles                                          (default 1)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)

@@ -150,7 +150,7 @@ struct CorrGemmArgs {
     int N, T, C;
     float sqrt_c, rcp_sqrt_c;
     int rcp_exact;   // sqrt(C) is a power of two
-    int xcd_rm, xcd_rn, xcd_maxreg, tiles_m, tiles_n;   // XCD-aware tile order (xcd_rm == 0: plain 3-D grid)
+    int xcd_rm, xcd_rn, xcd_maxreg, tiles_m, tiles_n, xcd_gw;   // XCD-aware tile order (xcd_rm == 0: plain 3-D grid)
 };
 
 constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32, CG_LD = 36;
@@ -179,10 +179,15 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
         const int rm = xcd / p.xcd_rn, rn = xcd - rm * p.xcd_rn;
         const int tm_lo = rm * p.tiles_m / p.xcd_rm, tm_hi = (rm + 1) * p.tiles_m / p.xcd_rm;
         const int tn_lo = rn * p.tiles_n / p.xcd_rn, tn_hi = (rn + 1) * p.tiles_n / p.xcd_rn;
-        const int nw = tn_hi - tn_lo;
-        if (nw <= 0 || t >= (tm_hi - tm_lo) * nw) return;      // workgroup-uniform: region smaller than the largest one
-        m0 = (tm_lo + t / nw) * CG_BM;
-        n0 = (tn_lo + t % nw) * CG_BN;
+        const int nw = tn_hi - tn_lo, mh = tm_hi - tm_lo;
+        if (nw <= 0 || t >= mh * nw) return;                    // workgroup-uniform: region smaller than the largest one
+        // inside the region: strips of xcd_gw n tiles, each walked m-major -- the strip's B panels (gw x 128 KB) are reused by
+        // every m row at once and the region's A panels (mh x 128 KB) return after mh * gw tiles, i.e. before the ~64 KB per
+        // tile of volume the L2 writes in between has pushed them out
+        const int gw = p.xcd_gw, g = t / (mh * gw), t_in = t - g * mh * gw;
+        const int wg = min(gw, nw - g * gw);
+        m0 = (tm_lo + t_in / wg) * CG_BM;
+        n0 = (tn_lo + g * gw + t_in % wg) * CG_BN;
     }
     const float *A = p.a + (int64_t)b * p.N * p.C;
     const float *Bm = p.bmat + (int64_t)b * p.T * p.C;
@@ -259,18 +264,24 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
             if (l < p.g.levels && n >= p.col_off[l]) lvl = l;
         const int64_t map = p.g.map[lvl];     // column n - col_off = float index inside the tiled map
         float *base = p.pyr + p.g.off[lvl] + (int64_t)b * p.N * map + (n - p.col_off[lvl]);
+        // corr.py:161 divides by sqrt(C); for C a power of four (256, 64) the reciprocal is exact and the product is the same
+        // float without the division sequence.  (Non-temporal stores measured no different in time or fabric reads:
+        // profiles/r10c_corr_build_ab.txt.)  Tiles that lie inside N (all of them at 448 x 512: 3584 = 28 x 128) take the
+        // branch-free path: one lane base, compile-time row offsets.
+        if (m0 + CG_BM <= p.N && p.rcp_exact) {   // workgroup-uniform
+            float *row0 = base + (int64_t)(m0 + wm * 64 + 4 * half) * map;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) row0[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * map] = acc[i][j][r] * p.rcp_sqrt_c;
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                // corr.py:161 divides by sqrt(C); for C a power of four (256, 64) the reciprocal is exact and the
-                // product is the same float without the division sequence
-                if (m < p.N) {
-                    const float val = p.rcp_exact ? acc[i][j][r] * p.rcp_sqrt_c : acc[i][j][r] / p.sqrt_c;
-                    // (non-temporal stores measured no different in time or fabric reads: profiles/r10c_corr_build_ab.txt)
-                    base[(int64_t)m * map] = val;
-                }
+                if (m < p.N) base[(int64_t)m * map] = p.rcp_exact ? acc[i][j][r] * p.rcp_sqrt_c : acc[i][j][r] / p.sqrt_c;
             }
         }
     }
@@ -314,7 +325,10 @@ extern "C" int raft_corr_build_f32(const float *fmap1, const float *fmap2, int B
     a.tiles_m = (int)raft_ceil_div(a.N, CG_BM);
     a.tiles_n = (int)raft_ceil_div(a.T, CG_BN);
     a.xcd_rm = a.xcd_rn = a.xcd_maxreg = 0;
-    if (raft_opt(RAFT_OPT_CORR_XCD, 1) != 0 && a.tiles_m * a.tiles_n >= 64) {   // small maps: nothing to gain, plain grid
+    a.xcd_gw = 2;   // fabric reads per pair at 8 pairs: plain grid 91 MB, regions walked n-fastest 63, strips of 8 / 4 / 2 tiles 43 / 38 / 36 (profiles/r10h_corr_build_ab.txt)
+    const int xcd_opt = raft_opt(RAFT_OPT_CORR_XCD, 1);       // 0: plain grid; 1: regions walked in 2-tile strips; n >= 2: strips of n tiles
+    if (xcd_opt > 1) a.xcd_gw = xcd_opt;
+    if (xcd_opt != 0 && a.tiles_m * a.tiles_n >= 64) {   // small maps: nothing to gain, plain grid
         a.xcd_rm = a.tiles_m >= 4 ? 4 : (a.tiles_m >= 2 ? 2 : 1);
         a.xcd_rn = 8 / a.xcd_rm;
         int mx = 0;

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=${1:-$root/gpurun_out/corr_build_ab.txt}
 : > $out
-for x in 0 1; do
+for x in ${XCD_VALUES:-0 1}; do
   for b in 4 8; do
     xx=$x
     d=/tmp/cb_${x}_$b; rm -rf $d; mkdir -p $d
