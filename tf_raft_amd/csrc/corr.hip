@@ -167,6 +167,9 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
     // plane of every batch element (xcd_rm x xcd_rn = 8 regions: 7 x 19 tiles each at 448x512) and walks it n-fastest: the ~64
     // workgroups an XCD holds at a time touch ~3.4 A panels and the region's 19 B panels (2.9 MB), and over a batch element an
     // XCD reads A/4 + B/2 = 3.4 MB instead of (nearly) all of A and B.
+    // (Two workgroups share a CU.  Delaying half of the first wave of workgroups by 11 - 30 us, so that co-resident pairs run
+    // out of phase, changed nothing -- 358 - 364 against 358 - 367 us, profiles/r10i_corr_stagger.txt: lock-step is not what
+    // keeps the MFMA pipe at 66 %.)
     int b, m0, n0;
     if (p.xcd_rm == 0) {
         b = blockIdx.z;
