@@ -97,7 +97,7 @@ def test_corr_build_matches_oracle_pyramid(rng, shape):
         assert err <= max(4 * err_ref, 2e-5)
 
 
-@pytest.mark.parametrize('shape', [(2, 56, 64, 256), (1, 44, 60, 64), (3, 128, 128, 32)])
+@pytest.mark.parametrize('shape', [(2, 56, 64, 256), (1, 44, 60, 64), (3, 128, 128, 32), (2, 44, 60, 128), (5, 56, 64, 256)])
 def test_corr_build_xcd_tile_order_is_bitwise_the_plain_grid(rng, shape, raft_opt):
     """The XCD-aware workgroup -> tile mapping of the volume build (one region of the tile plane per XCD; default) covers every
     tile exactly once: the whole pyramid, padding included, is bit for bit what the plain (n, m, batch) grid writes -- at the

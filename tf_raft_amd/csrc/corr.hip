@@ -154,6 +154,28 @@ struct CorrGemmArgs {
 };
 
 constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32, CG_LD = 36;
+#ifndef RAFT_GEMM_ABL
+#define RAFT_GEMM_ABL 0   // tools/ablate/lookup_layout.hip: 1 = no global loads / LDS writes after the first K step, 2 = no epilogue stores, 4 = no MFMAs
+#endif
+
+// XCD-aware tile order: tile `idx` of XCD `xcd` (idx = batch element * xcd_maxreg + position inside the XCD's region).  The
+// region is walked in strips of xcd_gw n tiles, each m-major -- the strip's B panels (gw x 128 KB) are reused by every m row at
+// once and the region's A panels (mh x 128 KB) return after mh * gw tiles, i.e. before the ~64 KB per tile of volume the L2
+// writes in between has pushed them out.  false: the position lies beyond this (smaller) region.
+__device__ __forceinline__ bool corr_xcd_tile(const CorrGemmArgs &p, int xcd, int idx, int &b, int &m0, int &n0) {
+    b = idx / p.xcd_maxreg;
+    const int t = idx - b * p.xcd_maxreg;
+    const int rm = xcd / p.xcd_rn, rn = xcd - rm * p.xcd_rn;
+    const int tm_lo = rm * p.tiles_m / p.xcd_rm, tm_hi = (rm + 1) * p.tiles_m / p.xcd_rm;
+    const int tn_lo = rn * p.tiles_n / p.xcd_rn, tn_hi = (rn + 1) * p.tiles_n / p.xcd_rn;
+    const int nw = tn_hi - tn_lo, mh = tm_hi - tm_lo;
+    if (nw <= 0 || t >= mh * nw) return false;
+    const int gw = p.xcd_gw, g = t / (mh * gw), t_in = t - g * mh * gw;
+    const int wg = min(gw, nw - g * gw);
+    m0 = (tm_lo + t_in / wg) * CG_BM;
+    n0 = (tn_lo + g * gw + t_in % wg) * CG_BN;
+    return true;
+}
 
 __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (CG_BM + CG_BN) * CG_LD];
@@ -164,9 +186,8 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
     const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
     // Workgroup -> tile.  xcd_rm == 0: the plain (n tile, m tile, batch) grid.  Otherwise (1-D grid) XCD-aware: the hardware
     // places workgroup i on XCD i % 8, and each XCD has an L2 of its own (4 MB) -- so XCD x owns one REGION of the (m tile, n tile)
-    // plane of every batch element (xcd_rm x xcd_rn = 8 regions: 7 x 19 tiles each at 448x512) and walks it n-fastest: the ~64
-    // workgroups an XCD holds at a time touch ~3.4 A panels and the region's 19 B panels (2.9 MB), and over a batch element an
-    // XCD reads A/4 + B/2 = 3.4 MB instead of (nearly) all of A and B.
+    // plane of every batch element (xcd_rm x xcd_rn = 8 regions: 7 x 19 tiles each at 448x512, corr_xcd_tile): over a batch
+    // element an XCD reads A/4 + B/2 = 3.4 MB instead of (nearly) all of A and B.
     // (Two workgroups share a CU.  Delaying half of the first wave of workgroups by 11 - 30 us, so that co-resident pairs run
     // out of phase, changed nothing -- 358 - 364 against 358 - 367 us, profiles/r10i_corr_stagger.txt: lock-step is not what
     // keeps the MFMA pipe at 66 %.)
@@ -175,22 +196,8 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
         b = blockIdx.z;
         m0 = blockIdx.y * CG_BM;
         n0 = blockIdx.x * CG_BN;
-    } else {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        b = idx / p.xcd_maxreg;
-        const int t = idx - b * p.xcd_maxreg;
-        const int rm = xcd / p.xcd_rn, rn = xcd - rm * p.xcd_rn;
-        const int tm_lo = rm * p.tiles_m / p.xcd_rm, tm_hi = (rm + 1) * p.tiles_m / p.xcd_rm;
-        const int tn_lo = rn * p.tiles_n / p.xcd_rn, tn_hi = (rn + 1) * p.tiles_n / p.xcd_rn;
-        const int nw = tn_hi - tn_lo, mh = tm_hi - tm_lo;
-        if (nw <= 0 || t >= mh * nw) return;                    // workgroup-uniform: region smaller than the largest one
-        // inside the region: strips of xcd_gw n tiles, each walked m-major -- the strip's B panels (gw x 128 KB) are reused by
-        // every m row at once and the region's A panels (mh x 128 KB) return after mh * gw tiles, i.e. before the ~64 KB per
-        // tile of volume the L2 writes in between has pushed them out
-        const int gw = p.xcd_gw, g = t / (mh * gw), t_in = t - g * mh * gw;
-        const int wg = min(gw, nw - g * gw);
-        m0 = (tm_lo + t_in / wg) * CG_BM;
-        n0 = (tn_lo + g * gw + t_in % wg) * CG_BN;
+    } else if (!corr_xcd_tile(p, blockIdx.x & 7, blockIdx.x >> 3, b, m0, n0)) {
+        return;                                                 // workgroup-uniform: region smaller than the largest one
     }
     const float *A = p.a + (int64_t)b * p.N * p.C;
     const float *Bm = p.bmat + (int64_t)b * p.T * p.C;
@@ -232,7 +239,7 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
     raft_barrier_lds();
     for (int s = 0; s < nk; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nk) gload((s + 1) * CG_BK);
+        if (s + 1 < nk && !(RAFT_GEMM_ABL & 1)) gload((s + 1) * CG_BK);
         const float *cA = sA + buf * CG_BM * CG_LD;
         const float *cB = sB + buf * CG_BN * CG_LD;
 #pragma unroll
@@ -250,9 +257,12 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
+                        if (RAFT_GEMM_ABL & 4)
+                            acc[i][j][r] += fa[i][r] * fb[j][r];
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
         }
-        if (s + 1 < nk) lstore(buf ^ 1);
+        if (s + 1 < nk && !(RAFT_GEMM_ABL & 1)) lstore(buf ^ 1);
         raft_barrier_lds();
     }
 
@@ -261,6 +271,7 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + l31;
         if (n >= p.T) continue;
+        if ((RAFT_GEMM_ABL & 2) && acc[0][j][0] != 12345.678f) continue;
         int lvl = 0;
 #pragma unroll
         for (int l = 1; l < RAFT_MAX_LEVELS; ++l)
@@ -290,6 +301,12 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
     }
 }
 
+// Round 4, measured and not kept (profiles/r10j_gemm_ablation.txt, r10k_corr_pipe_ab.txt): the phases of this kernel add up --
+// MFMA + fragment reads alone 273 us (131 TF) at 4 pairs, operand loads +44, volume stores +55 -- and two co-resident workgroups
+// do not hide them for each other.  A persistent variant (one workgroup per CU walking its XCD's tiles, the 64 stores per lane of
+// a finished tile issued under the next tile's first four K steps, the next tile's first stage fetched under the last K step;
+// bit-identical volume) was SLOWER, 387 against 357 us: gfx9's vmcnt counts stores and loads in one queue, so a wave that has
+// stores in flight waits for them whenever it waits for its next operand tile.
 extern "C" int raft_corr_build_f32(const float *fmap1, const float *fmap2, int B, int h, int w, int C,
                                    int levels, float *pyr, const int64_t *level_offsets, float *workspace,
                                    void *stream) {
