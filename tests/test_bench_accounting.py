@@ -82,3 +82,70 @@ def test_pmc_traffic_scales_the_committed_pass_per_pair():
         assert note['hbm_bytes_per_pair'] >= 0.99 * note['algorithmic_bytes_per_pair']
     assert bench.pmc_traffic('no_such_kernel', 4) == (None, None)
     assert bench.PEAK_FP32_MFMA_TFLOPS == 157.3 and bench.PEAK_HBM_GBS == 8000.0
+
+
+def test_parity_stats_reports_final_epe_horizon_and_locality():
+    """The EPE half of the metric (BASELINE.json: "final-iter EPE vs TF ref"): max over pixels of the 2-norm of the difference,
+    per iteration; horizon = first iteration beyond 1e-3; a departure is described by how local it is."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    want = [rng.normal(size=(1, 8, 8, 2)).astype(np.float32) for _ in range(6)]
+    got = [w.copy() for w in want]
+    for i in range(6):
+        got[i][0, 0, 0, 0] += np.float32(1e-5 * (i + 1))                      # slow drift on one pixel: stays inside
+    st = bench.parity_stats(got, want)
+    assert st['within_tol_on_every_iteration'] and st['iterations_within_tol'] == 6 and 'first_departure' not in st
+    assert st['final_iter_epe'] == pytest.approx(6e-5, rel=0.05) and len(st['per_iteration_epe']) == 6
+    got[3][0, 2, 2, :] += np.float32(0.3)                                      # a flipped tap at iteration 3: one pixel, 0.42 px
+    got[4][0, 2:4, 2:4, :] += np.float32(0.3)
+    got[5][0, 2:4, 2:4, :] += np.float32(0.3)
+    st = bench.parity_stats(got, want)
+    assert not st['within_tol_on_every_iteration'] and st['iterations_within_tol'] == 3
+    assert st['first_departure']['iteration'] == 3 and st['first_departure']['frac_pixels_within_tol'] == pytest.approx(63 / 64, abs=1e-4)
+    assert st['final_frac_pixels_within_tol'] == pytest.approx(60 / 64, abs=1e-4)
+    assert st['final_iter_epe'] == pytest.approx(0.3 * 2 ** 0.5, rel=1e-3)
+
+
+def test_evidence_files_are_flagged_stale_when_measured_on_other_sources(tmp_path, monkeypatch):
+    """profiles/pmc_traffic.json and kernel_durations.json record the digest of the HIP sources they were measured on; the bench
+    line must say so when that is not the library it runs (traffic figures from a pass that predated three kernel changes)."""
+    from tf_raft_amd import build
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    entry = {'batch': 8, 'in_loop': True, 'hbm_bytes_per_launch': 800, 'algorithmic_bytes_per_pair': 90, 'source': 'x.csv'}
+    (prof / 'pmc_traffic.json').write_text(json.dumps({'_meta': {'source_digest': build.source_digest(), 'git_head': 'abc'}, 'convc2': entry}))
+    tr, note = bench.pmc_traffic('convc2', 4)
+    assert tr == 400 and note['stale'] is False and note['measured_at_commit'] == 'abc' and note['hbm_bytes_per_pair'] == 100
+    (prof / 'pmc_traffic.json').write_text(json.dumps({'_meta': {'source_digest': 'digest-of-older-kernels'}, 'convc2': entry}))
+    assert bench.pmc_traffic('convc2', 4)[1]['stale'] is True
+    (prof / 'pmc_traffic.json').write_text(json.dumps({'convc2': entry}))               # a file from before round 4: no digest
+    assert bench.pmc_traffic('convc2', 4)[1]['stale'] is True
+    assert bench.pmc_traffic('no_such_stage', 4) == (None, None)
+    d, ev = bench.evidence_file('kernel_durations.json')                                 # absent
+    assert d is None and ev['present'] is False and ev['stale'] is True
+    (prof / 'kernel_durations.json').write_text(json.dumps({'_meta': {'source_digest': build.source_digest()}, 'b4': {'convc2': {'avg_us': 61.4}}}))
+    d, ev = bench.evidence_file('kernel_durations.json')
+    assert ev['stale'] is False and bench.rocprof_us(d, 4, 'convc2') == 61.4 and bench.rocprof_us(d, 8, 'convc2') is None
+
+
+def test_f4x4_launch_shape_follows_the_library_rule_and_its_hints():
+    """the launch block of the roofline object must come from the rule the library applies (grid size, RAFT_WINO4_KS,
+    the per-layer hints RAFT_CONVC2_KS / RAFT_CONVF2_KS), not from the grid size alone."""
+    from tf_raft_amd import _ffi
+    names = ('RAFT_WINO4_KS', 'RAFT_CONVC2_KS', 'RAFT_CONVF2_KS')
+    try:
+        for k in names:
+            _ffi.set_option(k, None)
+        assert bench.wino4_launch_shape('convc2', 4, 56, 64) == (168, True)       # 84 eight-row workgroups < 128: K split
+        assert bench.wino4_launch_shape('fh1_mask0', 4, 56, 64) == (224, False)
+        assert bench.wino4_launch_shape('convf2', 4, 56, 64) == (56, True)        # 28 eight-row workgroups: K split
+        assert bench.wino4_launch_shape('convf2', 8, 56, 64) == (56, False)       # 56 eight-row workgroups: the hint keeps them
+        assert bench.wino4_launch_shape('convc2', 8, 56, 64) == (168, False)
+        _ffi.set_option('RAFT_CONVC2_KS', 1)
+        assert bench.wino4_launch_shape('convc2', 4, 56, 64) == (84, False)
+        _ffi.set_option('RAFT_WINO4_KS', 2)                                        # the global switch wins over every hint
+        assert bench.wino4_launch_shape('convc2', 4, 56, 64) == (168, True) and bench.wino4_launch_shape('convf2', 8, 56, 64) == (112, True)
+    finally:
+        for k in names:
+            _ffi.set_option(k, None)
