@@ -16,18 +16,23 @@ N = 1 runs BASELINE configs[1] (batch 4 on the GPU); N > 1 runs configs[2]'s per
 on 8 GPUs) unless --batch says otherwise.
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
+  final_iter_epe      the EPE half of BASELINE's metric: max-abs EPE of flow_predictions[-1] (element 0 of the timed batch) against the
+                      CPU oracle, worst of the weight regimes where 1e-3 is provable (conditioned, jump0); `parity` holds all 24
+                      iterations, horizon and locality per regime (default = the weights `value` is timed on, conditioned, mid, jump0)
+  pairs_per_s_by_regime  the same step timed in every regime (3 interleaved rounds, median): no data-dependent work
   roofline            the dominant kernel (by accumulated time): achieved = the FLOPs the kernel EXECUTES on the MFMA
-                      pipe per launch / its HIP-event time net of the calibrated event bracket (the figure rocprofv3's kernel
-                      duration agrees with; achieved_between_events / frac_between_events = the raw interval, a strict
-                      upper bound on the kernel's duration), frac = achieved / 157.3 TF.  A layer on
+                      pipe per launch / its HIP-event time net of the calibrated event bracket; frac = achieved / 157.3 TF; `rocprof` =
+                      the same from the committed rocprofv3 durations (profiles/kernel_durations.json), with their staleness.  A layer on
                       a Winograd kernel executes fewer multiplies than the direct convolution it computes; the
                       direct-convolution figure is kept as algorithmic_tflops / frac_algorithmic (may exceed 1)
-  roofline_corr_lookup the HBM-bound lookup kernel the north star singles out
+  roofline_lookup_convc1_fused, roofline_mask_upsample_fused   the kernels the product loop runs
+  roofline_corr_lookup the HBM-bound stand-alone lookup the north star singles out, at 4 / 8 / 16 pairs, with its 0.60 target
   roofline_corr_build  the volume build: bound "mfma" (its GEMM) with the HBM write figure beside it
   traffic             HBM bytes per launch from the in-loop B=8 PMC passes of profiles/pmc_traffic.json (tools/pmc_traffic.sh),
-                      scaled per pair to this run's batch
+                      scaled per pair to this run's batch; `evidence` says whether those passes were taken on the running sources
   stage_ms            per-kernel average milliseconds per launch (HIP events, instrumented replay)
-  cpu_baseline        the CPU oracle (reference restatement, torch-CPU) timed on this box's host cores
+  cpu_baseline        the CPU oracle (reference restatement, torch-CPU) timed on this box's host cores, thread count probed
+  preflight           (N > 1) announced on stderr before timing: ranks seen, devices, libraft_hip.so mapped / not rebuilt per rank
 """
 import argparse
 import ctypes as C
