@@ -26,7 +26,6 @@
  * an atomic, it never calls getenv:
  *   RAFT_CONV_TILE      "<code>" or "<npad>:<taps>:<code>,...": tile of the direct convolution kernels
  *                       (100 + 10*TH + TN: TH x 16-pixel x 64*TN-channel halo tiles, TH in {4,7,8}, TN in {1,2})
- *   RAFT_CONV_DEEP      0/1  deep weight prefetch of the single-column-block halo tiles          (default 1)
  *   RAFT_CONV_WINO      bit mask {1 convc2, 2 convf2, 4 conv, 8 fh1_mask0}: layers on the F(2x2,3x3) kernel (13)
  *   RAFT_CONV_WINO4     the same mask (bit 2 = convf2) for the F(4x4,3x3) kernel, preferred where its bit is set and the 6x6-tap weights
  *                       were supplied        (default by launch size: 0 for a single 448x512 pair, 8 = fh1_mask0 from 2 pairs, + 1 | 2 = convc2, convf2 from 3, + 4 = conv from 8)
@@ -53,14 +52,12 @@
  *                       several tiles; 0 = one workgroup per tile)     (default 32; 0 where the chain's launches fill all CUs exactly)
  *   RAFT_CONVC2_KS      1/2  convc2 on the F(4x4) kernel in the loops: 8-row workgroups / K-split 4-row workgroups   (default: by grid size)
  *   RAFT_CONVF2_KS      1/2  the same for convf2                             (default: K-split below 56 eight-row workgroups)
- *   RAFT_GRU_Q_TNW      1/2  32- / 64-channel workgroups of the F(4,5) candidate-state convolutions            (default: by grid size)
  *   RAFT_EVENT_FENCE    0/1  cross-stream events of a raft_loop_ctx without / with the system-scope fence of a default HIP event
  *                            (read when the context is created)                                    (default 0: the events
  *                            only order streams of one device; +0.4 .. 0.9 %, profiles/r10c_event_fence.txt)
  *   RAFT_CORR_XCD       0/1/n  volume build: plain (n, m, batch) tile grid / one region of the tile plane per XCD, walked in strips
  *                            of 2 (n >= 2: n) column tiles                                          (default 1)
  *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
- *   RAFT_LOOKUP_LDS_PAD bytes of unused dynamic LDS (caps the lookup's workgroups per CU)        (default 0)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)
  *   RAFT_LOOP_GRAPH     0/1  three-stream loops replayed as one hipGraph launch                  (default 0: measured
  *                       slower than stream launches on ROCm 7.2 at every batch size)

@@ -212,7 +212,7 @@ static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weig
         a.wp = wino4.wp;
         a.bias = wino4.bias;
         a.npad = wino4.npad;
-        return raft_launch_conv_wino1d(a, kh, kw, epi, s, 4, epi == EPI_GRU_Q ? raft_opt(RAFT_OPT_GRU_Q_TNW, 0) : 0);
+        return raft_launch_conv_wino1d(a, kh, kw, epi, s, 4, 0);   // workgroup width by grid size (a forced 32- / 64-channel width for gru_q lost to it: profiles/r09q_gru_q_tnw.txt)
     }
     if ((mask & bit) && wino.wp != nullptr) {
         a.wp = wino.wp;

@@ -398,9 +398,9 @@ int raft_launch_conv_halo_1x5(const ConvArgs &a, int th, int tn, int epi, hipStr
 int raft_launch_conv_halo_5x1(const ConvArgs &a, int th, int tn, int epi, hipStream_t s);
 
 // Deep weight prefetch (DEEP = 1) for the single-column-block tiles: measured +2..4 % on every update-block layer at
-// B = 4 (profiles/r03j_conv_bench_deep*.txt), same register occupancy.  RAFT_CONV_DEEP = 0 switches it off (A/B timing).
+// B = 4 (profiles/r03j_conv_bench_deep*.txt), same register occupancy.
 static inline bool raft_conv_deep(const ConvArgs &, int, int tn, int) {
-    return tn == 1 && raft_opt(RAFT_OPT_CONV_DEEP, 1) != 0;
+    return tn == 1;
 }
 
 template <int KH, int KW, int EPI>

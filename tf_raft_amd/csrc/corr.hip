@@ -400,7 +400,7 @@ struct LookupArgs {
 // this one 12.0-12.9 us (367); a double-buffered multi-batch variant of it measured no better (13.4 us): the
 // kernel is bound by the lines its gathers pull, not by phase lock-step.
 #ifndef RAFT_LOOKUP_ABL
-#define RAFT_LOOKUP_ABL 0   // tools/ablate/lookup_abl.hip builds this file with pieces of the kernel switched off
+#define RAFT_LOOKUP_ABL 0   // tools/ablate/lookup_layout.hip can build this file with pieces of the kernel switched off (-DRAFT_LOOKUP_ABL=bits)
 #endif
 
 template <int R>
@@ -564,11 +564,10 @@ __global__ void __launch_bounds__(256) corr_lookup_strip_kernel(LookupArgs p) {
 template <int R>
 static void launch_lookup(const LookupArgs &a, bool staged, hipStream_t s) {
     const int grid = raft_ceil_div(a.nq, StripCfg<R>::QB);
-    const int pad = raft_opt(RAFT_OPT_LOOKUP_LDS_PAD, 0);   // tuning switch: unused dynamic LDS caps the workgroups per CU
     if (staged)
-        corr_lookup_strip_kernel<R, 1><<<grid, 256, pad, s>>>(a);
+        corr_lookup_strip_kernel<R, 1><<<grid, 256, 0, s>>>(a);
     else
-        corr_lookup_strip_kernel<R, 0><<<grid, 256, pad, s>>>(a);
+        corr_lookup_strip_kernel<R, 0><<<grid, 256, 0, s>>>(a);
 }
 
 extern "C" int raft_corr_lookup_f32(const float *pyr, const int64_t *level_offsets, const float *coords, int B,
