@@ -536,6 +536,15 @@ def main():
             regime_pred0[reg] = [p_.as_subclass(torch.Tensor)[:1].cpu().numpy() for p_ in preds]
             del preds
         del models
+    elif world > 1 and rank == 0 and not args.no_parity:
+        # N > 1: rank 0 alone evaluates the two provable regimes on ITS shard's element 0 (the other ranks wait at the closing
+        # barrier); the CPU oracle runs below, untimed -- cpu_baseline is an N = 1 figure
+        for reg in ('conditioned', 'jump0'):
+            regime_weights[reg] = wm.condition_weights('raft', wts, reg)
+            preds = tf_raft_amd.RAFT(iters_pred=ITERS, weights=regime_weights[reg])([img1, img2], training=False)
+            torch.cuda.synchronize()
+            regime_pred0[reg] = [p_.as_subclass(torch.Tensor)[:1].cpu().numpy() for p_ in preds]
+            del preds
 
     result = {
         'metric': METRIC, 'value': round(value, 3), 'unit': 'image-pairs/s',
@@ -895,7 +904,7 @@ def main():
 
         # ---------------- the EPE half of the metric + the CPU baseline: the oracle (reference restatement) on this box's host
         # cores, ONE (1,448,512,3) pair (element 0 of the timed batch), one timed forward per weight regime (same arithmetic)
-        if world == 1 and not args.no_cpu_baseline:
+        if (world == 1 and not args.no_cpu_baseline) or (world > 1 and regime_pred0):
             import oracle
             c1, c2 = img1[:1].cpu().numpy(), img2[:1].cpu().numpy()
             ncpu = os.cpu_count() or 1
@@ -911,12 +920,13 @@ def main():
                 times.append(time.perf_counter() - t0)
                 if i < len(regs) and reg in regime_pred0:
                     parity[reg] = parity_stats(regime_pred0[reg], want)
-            result['cpu_baseline'] = {
-                'value': round(1.0 / float(np.median(times)), 4), 'unit': 'image-pairs/s',
-                'cores': threads, 'host_cpus': ncpu, 'kind': 'port', 'runs_s': [round(t, 2) for t in times],
-                'sample': f'{len(times)} x (1,{H},{W},3) pair, iters_pred={ITERS}, torch-CPU fp32 restatement of the tf.keras path '
-                          f'(oracle/), one forward per weight regime {regs} (same arithmetic), median; {threads} threads = the fastest '
-                          f'of {cands} on a 2-iteration probe; TensorFlow itself is not installable here'}
+            if world == 1:
+                result['cpu_baseline'] = {
+                    'value': round(1.0 / float(np.median(times)), 4), 'unit': 'image-pairs/s',
+                    'cores': threads, 'host_cpus': ncpu, 'kind': 'port', 'runs_s': [round(t, 2) for t in times],
+                    'sample': f'{len(times)} x (1,{H},{W},3) pair, iters_pred={ITERS}, torch-CPU fp32 restatement of the tf.keras path '
+                              f'(oracle/), one forward per weight regime {regs} (same arithmetic), median; {threads} threads = the fastest '
+                              f'of {cands} on a 2-iteration probe; TensorFlow itself is not installable here'}
             if parity:
                 prov = [r for r in ('conditioned', 'jump0') if r in parity]
                 result['final_iter_epe'] = max(parity[r]['final_iter_epe'] for r in prov) if prov else None
