@@ -1,6 +1,8 @@
+#!/bin/bash
+# usage (GPU box, repo root, after tools/ablate/lookup_layout.sh build and the ablate_gemm_<bits> builds): bash tools/ablate/power_probe.sh
 # average power / clocks while one kernel variant loops for a few seconds (rocm-smi sampled every 0.2 s in the background)
 export TMPDIR=/tmp
-cd tools/ablate
+cd "$(dirname "$0")"
 for a in 0 3 5 4; do
   ( ./ablate_gemm_$a 4 24000 0 > /tmp/gemm_$a.txt 2>&1 ) &
   pid=$!
