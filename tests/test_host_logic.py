@@ -590,3 +590,20 @@ def test_conditioning_fixture_covers_the_cases_the_gpu_tests_gate_on():
     assert tuple(mid[k + 'bias']) == (np.float32(0.2), np.float32(-0.15)) and mid['fnet/conv1/kernel'] is w['fnet/conv1/kernel']
     with pytest.raises(ValueError):
         wm.condition_weights('raft', w, 'strong')
+
+
+def test_dropout_seeds_differ_by_rank_model_seed_and_step():
+    """the two dropout masks of a training step are seeded from (model seed, data-parallel rank, optimizer step) --
+    ranks see different shards and must not share masks, and a resumed run (optimizer.iterations restored) continues the
+    sequence instead of replaying it.  Seeds are even (the second mask uses seed + 1) and fit the C ABI's uint64."""
+    from tf_raft_amd.model import _dropout_seed
+    seen = set()
+    for seed in (0, 1, 7):
+        for rank in range(8):
+            for step in (1, 2, 3, 1000, 1001):
+                s = _dropout_seed(seed, rank, step)
+                assert s % 2 == 0 and 0 <= s < 2 ** 63
+                seen.add(s)
+                seen.add(s + 1)
+    assert len(seen) == 2 * 3 * 8 * 5
+    assert _dropout_seed(3, 2, 10) == _dropout_seed(3, 2, 10)
