@@ -36,7 +36,7 @@ fi
 [ -f $out/${tag}_pmc_traffic.json ] && cp $out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
 timeout 600 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_b4.log 2>&1
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $out/${tag}_prof -o bench -- python $root/bench.py --no-cpu-baseline --no-parity --steps 5 --warmup 2 > $out/${tag}_bench_b4_under_rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $out/${tag}_prof -o bench -- python $root/bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_b4_under_rocprof.log 2>&1
 f=$(ls $out/${tag}_prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_bench_b4_rocprofv3_kernel_stats.csv
 rm -rf $out/${tag}_prof
 timeout 200 rocprofv3 --kernel-trace -f csv -d $out/${tag}_tl -o tl -- python $root/tools/graph_probe.py 4 3 > $out/${tag}_tl.log 2>&1
