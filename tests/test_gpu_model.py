@@ -312,6 +312,29 @@ def test_north_star_free_running_final_prediction(variant, seed):
     assert _max_epe(_np(last), want[-1]) <= TOL
 
 
+@pytest.mark.parametrize('case', [('raft', 0, 'conditioned'), ('raft', 1, 'conditioned'), ('small', 0, 'conditioned'), ('raft', 0, 'jump0')])
+def test_north_star_against_the_reference_source_output(case):
+    """The same sentence against what the reference's OWN SOURCE produced: tests/golden/reference_forward_golden.npz holds
+    ``flow_predictions[-1]`` of /root/reference/tf_raft/model.py executed unmodified under oracle/tfstub (pixel grid [1::4, 2::4]
+    + whole-tensor checksums; tests/golden/make_reference_forward_golden.py).  No oracle code runs in this test."""
+    import sys
+    import tf_raft_amd
+    sys.path.insert(0, GOLDEN)
+    from make_conditioning import case_inputs, case_key
+    from make_reference_forward_golden import checksums, subsample
+    variant, seed, regime = case
+    z = np.load(os.path.join(GOLDEN, 'reference_forward_golden.npz'))
+    key = case_key(variant, 448, 512, 24, seed, regime)
+    i1, i2, wts = case_inputs(variant, 448, 512, seed, regime)
+    dcls = tf_raft_amd.RAFT if variant == 'raft' else tf_raft_amd.SmallRAFT
+    got = _np(dcls(weights=wts, iters_pred=24)([i1, i2])[-1])
+    err = _max_epe(subsample(got), z[f'{key}/last_grid'])
+    cs, want_cs = checksums(got), z[f'{key}/last_checksums']
+    report(f'north-star vs reference source {key}', final_epe_on_grid=err, rel_checksum=float(np.abs(cs / want_cs - 1).max()))
+    assert err <= TOL, err
+    np.testing.assert_allclose(cs[1:], want_cs[1:], rtol=1e-4)       # sum|f| and sum f^2 of ALL pixels (a flipped region would move them)
+
+
 def test_north_star_with_every_3x3_layer_on_winograd_f4x4(raft_opt):
     """The F(4x4,3x3) kernels are the default from 4 pairs on (checked per element by test_north_star_benchmarked_batches); here
     the single-pair north-star case is run with ALL THREE 3x3 layers of the update block forced onto them (RAFT_CONV_WINO4 = 13:
