@@ -16,9 +16,11 @@ N = 1 runs BASELINE configs[1] (batch 4 on the GPU); N > 1 runs configs[2]'s per
 on 8 GPUs) unless --batch says otherwise.
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  final_iter_epe      the EPE half of BASELINE's metric: max-abs EPE of flow_predictions[-1] (element 0 of the timed batch) against the
-                      CPU oracle, worst of the weight regimes where 1e-3 is provable (conditioned, jump0); `parity` holds all 24
-                      iterations, horizon and locality per regime (default = the weights `value` is timed on, conditioned, mid, jump0)
+  final_iter_epe      the EPE half of BASELINE's metric ON THE TIMED CONFIGURATION: max-abs EPE of flow_predictions[-1] (element 0 of the
+                      timed batch, Keras-default weights) against the CPU oracle; an untrained RAFT is ill conditioned there, so
+                      final_iter_epe_within_tolerance is false and final_iter_epe_default_horizon says how far 1e-3 holds.
+                      final_iter_epe_conditioned = worst of the regimes where 1e-3 is provable (conditioned, jump0); `parity` holds all 24
+                      iterations, horizon and locality per regime (default, conditioned, mid, jump0)
   pairs_per_s_by_regime  the same step timed in every regime (3 interleaved rounds, median): no data-dependent work
   roofline            the dominant kernel (by accumulated time): achieved = the FLOPs the kernel EXECUTES on the MFMA
                       pipe per launch / its HIP-event time net of the calibrated event bracket; frac = achieved / 157.3 TF; `rocprof` =
@@ -811,12 +813,19 @@ def main():
             lk['at_16_pairs'] = lookup_at(16)
             model._state = None                     # drop the 16-pair state buffers
             torch.cuda.empty_cache()
-        best = max(lk['frac_of_measured_copy'], lk.get('at_8_pairs', {}).get('frac_of_measured_copy', 0.0),
-                   lk.get('at_16_pairs', {}).get('frac_of_measured_copy', 0.0))
+        # the headline flag is the one at the batches BASELINE's configs use (configs[1]: 4 pairs, configs[2]: 8 per
+        # GPU); 16 pairs is reported beside them and earns nothing by itself.
+        by_batch = {B: lk['frac_of_measured_copy']}
+        for nb in (8, 16):
+            if f'at_{nb}_pairs' in lk:
+                by_batch[nb] = lk[f'at_{nb}_pairs']['frac_of_measured_copy']
+        baseline_batches = [nb for nb in (4, 8) if nb in by_batch]
         lk['target'] = {
-            'north_star': '>= 0.60 of the measured HBM copy rate on algorithmic bytes, by kernel duration', 'best_frac_of_measured_copy': best,
-            'target_met': bool(best >= 0.60),
-            'by_batch': {k: lk[k]['frac_of_measured_copy'] for k in ('at_8_pairs', 'at_16_pairs') if k in lk},
+            'north_star': '>= 0.60 of the measured HBM copy rate on algorithmic bytes, by kernel duration',
+            'frac_of_measured_copy_by_batch': {str(k): v for k, v in sorted(by_batch.items())},
+            'target_met_by_batch': {str(k): bool(v >= 0.60) for k, v in sorted(by_batch.items())},
+            'baseline_batches': baseline_batches,
+            'target_met': bool(baseline_batches) and all(by_batch[nb] >= 0.60 for nb in baseline_batches),
             'floor': 'PMC traffic is 1.32x the algorithmic bytes: a 10x10 footprint touches 6.9 128-byte lines of a 4x8-tiled map (3.1 '
                      'lines of useful floats), and the tile-shape study (profiles/r10b_lookup_layouts_*.txt: 8x4, 2x16, 4x4, 8x8, 2x8, '
                      'row-major; FETCH_SIZE / TCC_EA0_RDREQ per shape) shows the fetch granule is the 128-byte line and no shape pulls '
@@ -928,20 +937,32 @@ def main():
                               f'(oracle/), one forward per weight regime {regs} (same arithmetic), median; {threads} threads = the fastest '
                               f'of {cands} on a 2-iteration probe; TensorFlow itself is not installable here'}
             if parity:
+                # the top-level EPE fields describe the TIMED configuration (`value` is measured on the Keras-default
+                # weights); the regimes where the 1e-3 bound is provable are reported under their own name beside them.
                 prov = [r for r in ('conditioned', 'jump0') if r in parity]
-                result['final_iter_epe'] = max(parity[r]['final_iter_epe'] for r in prov) if prov else None
-                result['final_iter_epe_regimes'] = prov
-                result['final_iter_epe_within_tolerance'] = bool(prov) and all(parity[r]['within_tol_on_every_iteration'] for r in prov)
+                dflt = parity.get('default')
+                result['final_iter_epe'] = dflt['final_iter_epe'] if dflt else None
+                result['final_iter_epe_regime'] = 'default (the weights `value` is timed on)' if dflt else None
+                result['final_iter_epe_within_tolerance'] = bool(dflt and dflt['within_tol_on_every_iteration'])
+                if dflt:
+                    result['final_iter_epe_default_horizon'] = {
+                        'iterations_within_tol': dflt['iterations_within_tol'], 'of': ITERS,
+                        'final_frac_pixels_within_tol': dflt.get('final_frac_pixels_within_tol', 1.0)}
+                result['final_iter_epe_conditioned'] = max(parity[r]['final_iter_epe'] for r in prov) if prov else None
+                result['final_iter_epe_conditioned_regimes'] = prov
+                result['final_iter_epe_conditioned_within_tolerance'] = bool(prov) and all(parity[r]['within_tol_on_every_iteration'] for r in prov)
                 result['final_iter_epe_by_regime'] = {r: parity[r]['final_iter_epe'] for r in parity}
                 result['parity'] = {
                     'tolerance': EPE_TOL, 'compared': 'flow_predictions[0..23] of element 0 of the timed batch (HIP, computed inside the '
                     f'batch of {B}) against the CPU oracle run on that pair alone; max over pixels of the 2-norm of the difference',
-                    'reference': 'oracle/ = CPU restatement of the reference (TensorFlow 2.3 is not installable here: parity vs the '
-                                 'restatement, whole-forward value unpinned -- DESIGN.md section 2)',
+                    'reference': 'oracle/ = CPU restatement of the reference, asserted bit-equal to the reference\'s unmodified source run '
+                                 'on a stand-in tensorflow (tests/test_reference_under_stub.py); TensorFlow 2.3 itself is not installable '
+                                 'here, so the semantics of the TF primitives remain recalled -- DESIGN.md section 2',
                     'regimes': parity,
                     'note': 'default = the weights `value` is timed on: an untrained RAFT is ill conditioned there (any two fp32 evaluations '
                             'part ways at the first flipped tap), so it is reported by horizon and locality; conditioned / jump0 are the '
-                            'regimes where the 1e-3 bound is provable and final_iter_epe is their worst'}
+                            'regimes where the 1e-3 bound is provable: final_iter_epe_conditioned is their worst.  final_iter_epe (top level) is the '
+                            'default regime, i.e. the timed configuration, and is NOT within tolerance there'}
         if regime_rate:
             result['pairs_per_s_by_regime'] = regime_rate
             lo, hi = min(regime_rate.values()), max(regime_rate.values())
@@ -950,8 +971,9 @@ def main():
             result['regime_timing'] = (f'{len(next(iter(regime_rounds.values())))} interleaved rounds of {args.steps} steps per regime in this '
                                        'process (same inputs, same launches; only the weights differ), median per regime; `value` is the '
                                        'separately timed headline on the default weights')
-        front = ['metric', 'value', 'unit', 'final_iter_epe', 'final_iter_epe_regimes', 'final_iter_epe_within_tolerance',
-                 'final_iter_epe_by_regime', 'pairs_per_s_by_regime', 'regime_spread_frac']
+        front = ['metric', 'value', 'unit', 'final_iter_epe', 'final_iter_epe_regime', 'final_iter_epe_within_tolerance',
+                 'final_iter_epe_default_horizon', 'final_iter_epe_conditioned', 'final_iter_epe_conditioned_regimes',
+                 'final_iter_epe_conditioned_within_tolerance', 'final_iter_epe_by_regime', 'pairs_per_s_by_regime', 'regime_spread_frac']
         result = {**{k: result[k] for k in front if k in result}, **{k: v for k, v in result.items() if k not in front}}
         print(json.dumps(result), flush=True)
         try:

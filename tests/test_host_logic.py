@@ -493,10 +493,14 @@ def test_a_stale_library_is_never_loaded_silently(monkeypatch):
     monkeypatch.setattr(build, 'built_digest', build.source_digest)
     with pytest.warns(RuntimeWarning, match='up-to-date'):
         _ffi.load_library()
-    # a prebuilt .so that arrived WITHOUT its stamp (box without hipcc) cannot be verified: it loads with a
-    # warning that says so, and the ABI check still applies
+    # a prebuilt .so that arrived WITHOUT its stamp cannot be verified: refused unless the caller opts in, then
+    # loaded with a warning that says so; the ABI check still applies
     monkeypatch.setattr(_ffi, '_LIB', None)
     monkeypatch.setattr(build, 'built_digest', lambda: None)
+    monkeypatch.delenv('RAFT_ALLOW_UNVERIFIED_LIB', raising=False)
+    with pytest.raises(RuntimeError, match='no build stamp'):
+        _ffi.load_library()
+    monkeypatch.setenv('RAFT_ALLOW_UNVERIFIED_LIB', '1')
     with pytest.warns(RuntimeWarning, match='UNVERIFIED'):
         assert _ffi.load_library().raft_version() == _ffi.ABI_VERSION
 

@@ -154,8 +154,8 @@ def load_library():
     """Load and type the library.  When hipcc is available the build is refreshed first (a digest of sources + flags
     makes that a no-op for an up-to-date .so), so a stale library never meets newer struct mirrors.  When the refresh
     fails (no hipcc, read-only tree, compile error) an existing .so is used only if its build stamp (lib/build.sha256,
-    shipped beside it) matches the sources on disk; a .so WITHOUT a stamp cannot be verified and is loaded with a warning
-    (the ABI check below still applies); a stamp that names other sources is refused unless RAFT_ALLOW_STALE_LIB=1.
+    shipped beside it) matches the sources on disk; a .so WITHOUT a stamp cannot be verified and is refused unless
+    RAFT_ALLOW_UNVERIFIED_LIB=1; a stamp that names other sources is refused unless RAFT_ALLOW_STALE_LIB=1.
     Either way ``raft_version()`` must equal ``ABI_VERSION``."""
     global _LIB
     if _LIB is not None:                       # fast path: no lock once loaded
@@ -181,6 +181,10 @@ def load_library():
                 raise RuntimeError(
                     f'{path} was built from different sources than the ones on disk and rebuilding failed: {exc}.  '
                     'Fix the build, or set RAFT_ALLOW_STALE_LIB=1 to load the old library knowingly') from exc
+            if unknown and '1' not in (os.environ.get('RAFT_ALLOW_UNVERIFIED_LIB'), os.environ.get('RAFT_ALLOW_STALE_LIB')):
+                raise RuntimeError(
+                    f'{path} carries no build stamp (lib/build.sha256), so it cannot be checked against the sources on disk, and '
+                    f'rebuilding failed: {exc}.  Fix the build, or set RAFT_ALLOW_UNVERIFIED_LIB=1 to load it knowingly') from exc
             import warnings
             warnings.warn(f'libraft_hip.so could not be refreshed ({exc}); loading the existing '
                           f'{"STALE " if stale else ("UNVERIFIED (no build stamp) " if unknown else "up-to-date ")}library at {path}',
