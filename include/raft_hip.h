@@ -72,7 +72,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 215          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 216          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -175,6 +175,13 @@ int raft_upflow8_f32(const float *flow, int B, int h, int w, float *out, void *s
  * the box it runs on -- the "measured roofline" the lookup / build / upsample kernels are quoted
  * against next to the 8 TB/s datasheet figure. */
 int raft_stream_copy_f32(const float *src, float *dst, int64_t n, void *stream);
+
+/* Measurement utility (no reference counterpart): `blocks` workgroups of 256 threads, every wave issuing `iters` x 8
+ * independent v_mfma_f32_16x16x4_f32 (nothing else in the loop; non-zero lane-varying operands); out: blocks * 256
+ * floats (written so that the loop cannot be optimised away).  FLOPs = blocks * 4 * iters * 8 * 2048.  bench.py times it
+ * to state the fp32-MFMA rate the box SUSTAINS (power-limited clock) next to the 157.3 TFLOP/s datasheet figure every
+ * `roofline.frac` is quoted against. */
+int raft_mfma_probe_f32(float *out, int blocks, int iters, void *stream);
 
 /* ------------------------------------------------------------------ convolutions */
 

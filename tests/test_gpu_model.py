@@ -681,6 +681,78 @@ def test_alternate_corr_model_matches_volume_model():
     assert max(errs) <= TOL
 
 
+@pytest.mark.parametrize('variant,kw,shape,iters', [('raft', {}, (2, 128, 192), 6), ('raft', {}, (4, 448, 512), 5), ('small', {}, (2, 128, 192), 6),
+                                                     ('raft', {'alternate_corr': True}, (1, 256, 320), 4)])
+def test_pipelined_calls_are_bitwise_the_serial_calls(variant, kw, shape, iters):
+    """Round 5: consecutive inference calls overlap -- the loop of call n runs on the 'loop' stream while the caller's stream
+    already runs the encoders and the volume build of call n + 1 (tf_raft_amd/model.py, "pipelined forward").  Every call's
+    24 predictions must equal, bit for bit, what an isolated call of a serial (pipeline=False) model returns for the same
+    inputs: 5 back-to-back calls on different inputs whose results are not touched until all are enqueued (UpdateState ring
+    reused twice), results consumed out of order, then dropped while later loops are still in flight."""
+    import tf_raft_amd
+    from tf_raft_amd import weights as wm
+    cls = tf_raft_amd.RAFT if variant == 'raft' else tf_raft_amd.SmallRAFT
+    wts = wm.init_weights(variant, seed=3, perturb=True)
+    B, H, W = shape
+    pipe = cls(weights=wts, iters_pred=iters, pipeline=True, **kw)
+    serial = cls(weights=wts, iters_pred=iters, pipeline=False, **kw)
+    assert pipe.pipeline and not serial.pipeline
+    inputs = [tuple(torch.as_tensor(a).cuda() for a in _images(40 + k, B, H, W)) for k in range(5)]
+    torch.cuda.synchronize()
+    outs = [pipe([a, b]) for a, b in inputs]                       # nothing touches the results: five calls in flight
+    junk = [torch.full((1 << 22,), float(k), device='cuda') for k in range(4)]     # allocator traffic on the caller's stream
+    order = [3, 0, 4, 1, 2]
+    got = {k: [o.cpu().numpy() for o in outs[k]] for k in order}
+    del outs, junk
+    for k, (a, b) in enumerate(inputs):
+        want = serial([a, b])
+        torch.cuda.synchronize()
+        assert len(want) == iters
+        for g, w_ in zip(got[k], want):
+            np.testing.assert_array_equal(g, w_.cpu().numpy())
+    # results dropped at once while their loops run; the allocator must not hand their memory to the next call early
+    last = None
+    for k in range(5):
+        a, b = inputs[k]
+        last = pipe([a, b])
+        if k < 4:
+            del last
+            torch.empty((iters, B, H, W, 2), device='cuda').fill_(float('nan'))
+    np.testing.assert_array_equal(last[-1].cpu().numpy(), got[4][-1])
+    if variant == 'raft' and not kw:
+        # predict_step (final-only loop) through the same pipeline, shape change in between (ring re-allocation)
+        ps = [pipe.predict_step((a, b)) for a, b in inputs[:3]]
+        small_in = tuple(torch.as_tensor(x).cuda() for x in _images(77, 1, 64, 96))
+        other = pipe.predict_step(small_in)
+        for k in range(3):
+            np.testing.assert_array_equal(ps[k].cpu().numpy(), got[k][-1])
+        np.testing.assert_array_equal(other.cpu().numpy(), serial.predict_step(small_in).cpu().numpy())
+
+
+def test_pending_results_join_whichever_stream_touches_them_first():
+    """A pipelined result waits for its loop on the stream that first touches its data -- a side stream here -- and metadata
+    reads do not wait."""
+    import tf_raft_amd
+    from tf_raft_amd import _dev
+    model = tf_raft_amd.RAFT(iters_pred=8, pipeline=True)
+    serial = tf_raft_amd.RAFT(iters_pred=8, pipeline=False)
+    a, b = (torch.as_tensor(x).cuda() for x in _images(5, 2, 128, 192))
+    want = serial([a, b])[-1].cpu().numpy()
+    out = model([a, b])
+    p = out[-1].__dict__['_pending']
+    assert tuple(out[-1].shape) == (2, 128, 192, 2) and out[-1].dtype == torch.float32 and not p._joined     # no join for metadata
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        doubled = out[-1] * 2                       # first touch: on `side`
+        assert p._joined == {side.cuda_stream}
+    side.synchronize()
+    np.testing.assert_array_equal(doubled.cpu().numpy(), want * 2)
+    raw = out[-1].as_subclass(torch.Tensor)          # as_subclass is not a torch function: joins explicitly
+    assert torch.cuda.current_stream().cuda_stream in p._joined
+    np.testing.assert_array_equal(raw.cpu().numpy(), want)
+    assert _dev.join(out) is out
+
+
 def test_three_stream_loop_is_bitwise_the_single_stream_loop():
     """raft_iterate_basic_overlap_f32 (flow / mask branches on side streams) must reproduce
     raft_iterate_basic_f32 bit for bit on every prediction, repeatedly (no races)."""

@@ -23,9 +23,67 @@ def require_gpu() -> torch.device:
     return torch.device('cuda', torch.cuda.current_device())
 
 
+class Pending:
+    """Results still being computed on another stream than the caller's (the pipelined forward of ``tf_raft_amd.model``: the
+    recurrent loop runs on the process-wide 'loop' stream so that the NEXT call's encoders can run under it).  ``join()`` makes
+    the CURRENT stream wait for them, once per stream; every route from a ``DeviceTensor`` to its bytes calls it first."""
+
+    __slots__ = ('event', 'device', '_joined')
+
+    def __init__(self, event, device):
+        self.event, self.device, self._joined = event, device, set()
+
+    def join(self):
+        try:
+            sid = torch._C._cuda_getCurrentRawStream(self.device.index)
+        except AttributeError:
+            sid = torch.cuda.current_stream(self.device).cuda_stream
+        if sid not in self._joined:
+            torch.cuda.current_stream(self.device).wait_event(self.event)
+            self._joined.add(sid)
+
+
+# attribute reads that say nothing about the tensor's bytes: no ordering needed
+_METADATA = frozenset(('shape', 'dtype', 'device', 'is_cuda', 'ndim', 'layout', 'requires_grad', 'grad', 'grad_fn', 'is_leaf',
+                       'names', 'is_sparse', 'is_quantized', 'is_meta', 'output_nr', '_version', 'is_cpu', 'itemsize', 'nbytes'))
+
+
 class DeviceTensor(torch.Tensor):
     """A device tensor that also answers ``.numpy()`` / ``np.asarray`` like the TF eager tensors
-    the reference returns (reference model.py:109), by copying to the host first."""
+    the reference returns (reference model.py:109), by copying to the host first.
+
+    A tensor returned by a pipelined forward call carries a ``Pending``: the first operation that touches its data (any
+    torch function or method, ``data_ptr()``, ``as_subclass``, ``numpy()``) makes the current stream wait for the loop that
+    produces it.  Reading ``shape`` / ``dtype`` / ``device`` does not."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if not (getattr(func, '__name__', '') == '__get__' and getattr(getattr(func, '__self__', None), '__name__', '') in _METADATA):
+            for a in args:
+                if type(a) is DeviceTensor:
+                    p = a.__dict__.get('_pending')
+                    if p is not None:
+                        p.join()
+                elif type(a) in (list, tuple):
+                    for b in a:
+                        if type(b) is DeviceTensor and b.__dict__.get('_pending') is not None:
+                            b.__dict__['_pending'].join()
+            if kwargs:
+                for a in kwargs.values():
+                    if type(a) is DeviceTensor and a.__dict__.get('_pending') is not None:
+                        a.__dict__['_pending'].join()
+        return super().__torch_function__(func, types, args, kwargs or {})
+
+    def join(self):
+        """Make the current stream wait for this tensor's producer (no-op for a tensor that is not pending)."""
+        p = self.__dict__.get('_pending')
+        if p is not None:
+            p.join()
+        return self
+
+    def as_subclass(self, cls):   # type: ignore[override]   (not routed through __torch_function__)
+        self.join()
+        return super().as_subclass(cls)
 
     def numpy(self):   # type: ignore[override]
         return self.detach().as_subclass(torch.Tensor).cpu().numpy()
@@ -35,8 +93,19 @@ class DeviceTensor(torch.Tensor):
         return a if dtype is None else a.astype(dtype)
 
 
-def wrap(t: torch.Tensor) -> torch.Tensor:
-    return t.as_subclass(DeviceTensor)
+def wrap(t: torch.Tensor, pending: 'Pending' = None) -> torch.Tensor:
+    d = t.as_subclass(DeviceTensor)
+    if pending is not None:
+        d.__dict__['_pending'] = pending
+    return d
+
+
+def join(t):
+    """Order the current stream behind whatever still produces ``t`` (a tensor or a list of them); returns ``t``."""
+    for x in (t if isinstance(t, (list, tuple)) else (t,)):
+        if isinstance(x, DeviceTensor):
+            x.join()
+    return t
 
 
 def to_device(x, device=None, dtype=torch.float32) -> torch.Tensor:
@@ -75,13 +144,14 @@ def stream_ptr() -> int:
 _SIDE_STREAMS = {}
 
 
-def side_stream(device, role: str) -> 'torch.cuda.Stream':
-    """The process-wide side stream of ``role`` ('flow', 'mask', 'encoder', 'loop') on ``device``."""
+def side_stream(device, role: str, priority: int = 0) -> 'torch.cuda.Stream':
+    """The process-wide side stream of ``role`` ('flow', 'mask', 'encoder', 'loop') on ``device`` (``priority`` applies when
+    the stream is first created)."""
     device = torch.device(device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), role)
     s = _SIDE_STREAMS.get(key)
     if s is None:
-        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
     return s
 
 

@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 215     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 216     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -75,6 +75,7 @@ _SIGNATURES = {
     'raft_upsample_convex_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'raft_upflow8_f32': (_I, [_P, _I, _I, _I, _P, _P]),
     'raft_stream_copy_f32': (_I, [_P, _P, C.c_int64, _P]),
+    'raft_mfma_probe_f32': (_I, [_P, _I, _I, _P]),
     'raft_metrics_workspace_doubles': (C.c_int64, []),
     'raft_flow_metrics_f32': (_I, [_P, _P, _P, C.c_int64, C.c_float, _P, _P, _P]),
     'raft_sequence_loss_f32': (_I, [_P, _P, _P, C.c_int64, _I, C.c_int64, C.c_double, C.c_float, _P, _P, _P]),

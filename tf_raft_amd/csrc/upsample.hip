@@ -148,3 +148,34 @@ extern "C" int raft_stream_copy_f32(const float *src, float *dst, int64_t n, voi
     stream_copy_kernel<<<raft_ceil_div(n4, 256), 256, 0, (hipStream_t)stream>>>((const f32x4 *)src, (f32x4 *)dst, n4);
     return raft_launch_status();
 }
+
+// Measurement utility: what the fp32 matrix pipe of THIS box sustains.  Every wave runs `iters` trips of 8 independent
+// v_mfma_f32_16x16x4_f32 accumulation chains on loop-invariant, lane-varying, non-zero operands (nothing else in the loop: no
+// loads, no VALU), 2 waves per SIMD, `blocks` workgroups of 256 threads.  FLOPs = blocks * 4 * iters * 8 * 2048.
+__global__ void __launch_bounds__(256, 2) mfma_probe_kernel(float *__restrict__ out, int iters) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x;
+    float a[8], b[8];
+    f32x4_t acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j] = 0.5f + 0.0013f * (float)((t * 37 + j * 11) & 255);
+        b[j] = 1.25f - 0.0021f * (float)((t * 53 + j * 7) & 255);
+        acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    out[(int64_t)blockIdx.x * 256 + t] = s;
+}
+
+extern "C" int raft_mfma_probe_f32(float *out, int blocks, int iters, void *stream) {
+    RAFT_REQUIRE_PTR(out);
+    RAFT_REQUIRE(blocks > 0 && iters > 0, RAFT_E_SHAPE);
+    mfma_probe_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(out, iters);
+    return raft_launch_status();
+}

@@ -29,9 +29,10 @@ def _f32(t):
 # Keyed by the identity of the source array (kept alive by the entry) AND validated against a version: parameters may be
 # device tensors that the optimizer and the batch-norm statistics update IN PLACE, so identity alone would hand back the
 # packed copy of the old values.  The version of an entry is (torch's in-place counter of each source tensor, the module
-# counter that ``bump_pack_version()`` advances); ``training.AdamW.apply_gradients`` and the moving-statistics update call
-# ``bump_pack_version()`` after writing through raw pointers (HIP kernels do not advance torch's counter), and
-# ``RAFT.train_step`` still clears the cache at the start of every step to bound its size.
+# counter that ``bump_pack_version()`` advances); ``training.AdamW.apply_gradients`` and ``RAFT.train_step``'s moving-statistics
+# update call ``bump_pack_version()`` after writing (HIP kernels behind raw pointers do not advance torch's counter), and
+# ``RAFT.train_step`` still clears the cache at the start of every step to bound its size.  Any other raw-pointer writer of a
+# parameter tensor has to call it too.
 _PACK = {}
 _PACK_VERSION = [0]
 

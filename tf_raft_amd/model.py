@@ -66,7 +66,7 @@ class RAFT:
     variant = 'raft'
 
     def __init__(self, drop_rate=0, iters=12, iters_pred=24, weights: Optional[Dict[str, np.ndarray]] = None,
-                 seed=0, alternate_corr=False, overlap=None, **kwargs):
+                 seed=0, alternate_corr=False, overlap=None, pipeline=None, **kwargs):
         # reference model.py:11-12 forwards **kwargs to tf.keras.Model, whose constructor takes `name` (and nothing a
         # forward pass depends on): accept it, reject the rest
         self.name = kwargs.pop('name', type(self).__name__.lower())
@@ -83,9 +83,13 @@ class RAFT:
         self.alternate_corr = alternate_corr
         # three-stream schedule of the loop (RAFT only); RAFT_OVERLAP=0 forces the single-stream loop
         self.overlap = (os.environ.get('RAFT_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
+        # consecutive inference calls overlap (section "pipelined forward" below); RAFT_PIPELINE=0 restores the serial schedule
+        self.pipeline = (os.environ.get('RAFT_PIPELINE', '1') != '0') if pipeline is None else bool(pipeline)
         self._aux = None
         self._enc_stream = None
         self._state = None
+        self._ring = [None, None]               # pipelined forward: (UpdateState, loop-done event) per slot
+        self._calls = 0
         self._loop_ctx = None
         self._loop_stream = None
         _dev.require_gpu()
@@ -285,6 +289,8 @@ class RAFT:
         if H % 8 or W % 8:
             raise ValueError(f'H and W must be multiples of 8 (got {H}x{W})')   # model.py:35 uses h//8
         # model.py:70-71 (2 * (image / 255) - 1) is applied by the encoders while they stage the image
+        if self.pipeline and self.overlap and not training:
+            return self._forward_pipelined(image1, image2, final_only)
         if self.overlap and not training:
             # the context encoder does not depend on the feature encoder or the volume: it runs on a side stream
             # next to them (its one-workgroup-per-CU layers fill the tails of the feature encoder's launches)
@@ -310,22 +316,90 @@ class RAFT:
             st = self._get_state(B, h, w, image1.device)
             self._prepare(cnet, st)                                             # model.py:84-89
         iters = self.iters if training else self.iters_pred
+        out = self._run_loop(correlation, st, iters, self._alloc_out(iters, B, H, W, image1.device, final_only), final_only)
+        return _dev.wrap(out) if final_only else [_dev.wrap(out[i]) for i in range(iters)]   # model.py:109
+
+    @staticmethod
+    def _alloc_out(iters, B, H, W, dev, final_only):
+        return torch.empty((B, H, W, 2) if final_only else (iters, B, H, W, 2), device=dev, dtype=torch.float32)
+
+    def _run_loop(self, correlation, st, iters, out, final_only):
+        """model.py:93-109 on the CURRENT stream (+ the two aux streams of the three-stream schedule) into ``out``."""
+        B, h, w = st.B, st.h, st.w
         if final_only:
-            last = torch.empty((B, H, W, 2), device=image1.device, dtype=torch.float32)
+            last = out
             with self._capturable_stream(last.device):
                 check(_dev.lib().raft_iterate_basic_final_f32(
                     C.byref(self.update_block.c), _dev.ptr(correlation._pyr), correlation._off, B, h, w, iters, C.byref(st.c),
                     _dev.ptr(last), _dev.stream_ptr(), self._aux_streams(last.device)[0].cuda_stream,
                     self._aux_streams(last.device)[1].cuda_stream, self._loop_context(last.device)), 'iterate_basic_final')
             self._last_correlation = correlation
-            return _dev.wrap(last)
-        flow_up = torch.empty((iters, B, H, W, 2), device=image1.device, dtype=torch.float32)
+            return last
+        flow_up = out
         if self.alternate_corr:
             self._iterate_alternate(correlation, st, iters, flow_up)
         else:
             self._iterate(correlation, st, iters, flow_up)                      # model.py:93-106
         self._last_correlation = correlation                                    # keep buffers alive until the stream drains
-        return [_dev.wrap(flow_up[i]) for i in range(iters)]                    # model.py:109
+        return flow_up
+
+    # ---- pipelined forward ------------------------------------------------------------------------------------------------
+    # One inference call = encoders + volume build (2.96 of 12.3 ms at 4 pairs, kernels that fill the chip) followed by the 24
+    # iterations of a DEPENDENT chain whose launches leave 32 .. 88 of the 256 CUs idle.  Back-to-back calls are independent of
+    # each other, so call n + 1's pre-loop work can run under call n's loop: the loop is enqueued on the process-wide 'loop'
+    # stream (its flow / mask branches on the aux streams, as before), the pre-loop work stays on the caller's stream, and the
+    # caller's stream is NOT made to wait for the loop -- the returned tensors carry a `_dev.Pending` and whichever stream first
+    # touches their data waits for the loop then (a caller that consumes the result at once sees the serial schedule).  What
+    # makes this safe: the loop's inputs that the next call would overwrite exist twice (UpdateState ring; call n + 2's
+    # pre-loop waits for loop n's event before it touches slot n & 1), per-call allocations read or written by the loop
+    # (volume, feature maps of the on-demand lookup, the predictions) are recorded on the loop stream so the caching allocator
+    # cannot hand them out before the loop has finished, and loops of consecutive calls follow each other in stream order.
+    # Per-call results are bit-identical to the serial schedule (same kernels, same order per call):
+    # tests/test_gpu_model.py::test_pipelined_calls_are_bitwise_the_serial_calls.
+    def _ring_state(self, slot, B, h, w, device):
+        ent = self._ring[slot]
+        if ent is None or (ent[0].B, ent[0].h, ent[0].w) != (B, h, w) or ent[0].net.device != device:
+            if ent is not None and ent[1] is not None:
+                ent[1].synchronize()                     # the old buffers are about to be freed: their last loop must be done
+            ent = self._ring[slot] = [UpdateState(self.variant, B, h, w, device), None]
+        return ent
+
+    def _forward_pipelined(self, image1, image2, final_only):
+        B, H, W, _ = image1.shape
+        h, w = H // 8, W // 8
+        dev = image1.device
+        cur = torch.cuda.current_stream(dev)
+        prio = -1 if os.environ.get('RAFT_LOOP_PRIORITY', '0') == '1' else 0
+        loop = _dev.side_stream(dev, 'loop', priority=prio)
+        if self._aux is None or self._aux[0].device != dev:
+            self._aux = (_dev.side_stream(dev, 'flow', priority=prio), _dev.side_stream(dev, 'mask', priority=prio))
+        slot = self._calls & 1
+        self._calls += 1
+        ent = self._ring_state(slot, B, h, w, dev)
+        st = ent[0]
+        if ent[1] is not None:
+            cur.wait_event(ent[1])                       # slot's previous user (call n - 2): its loop read this state
+        cnet = self.cnet(image1, training=False, _raw_images=True)                      # model.py:82
+        self._prepare(cnet, st)                                                          # model.py:84-89
+        fmap1, fmap2 = self.fnet([image1, image2], training=False, _raw_images=True)    # model.py:74
+        correlation = CorrBlock(fmap1, fmap2, num_levels=self.corr_levels, radius=self.corr_radius,
+                                alternate=self.alternate_corr)                           # model.py:77
+        out = self._alloc_out(self.iters_pred, B, H, W, dev, final_only)      # from the caller's stream's pool, like every other buffer
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        loop.wait_event(ready)
+        with torch.cuda.stream(loop):
+            self._run_loop(correlation, st, self.iters_pred, out, final_only)
+            done = torch.cuda.Event()
+            done.record(loop)
+        for t in (out, getattr(correlation, '_pyr', None), getattr(correlation, '_f2pyr', None), correlation.fmap1, correlation.fmap2):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.as_subclass(torch.Tensor).record_stream(loop)      # allocated under `cur`, in use on `loop`
+        ent[1] = done
+        pending = _dev.Pending(done, dev)
+        if final_only:
+            return _dev.wrap(out, pending)
+        return [_dev.wrap(out[i], pending) for i in range(self.iters_pred)]             # model.py:109
 
     def predict_step(self, data):
         """reference model.py:160-166: ``flow_predictions[-1]`` of the forward pass.  RAFT computes it with the mask head
@@ -380,13 +454,14 @@ class RAFT:
             filled += got.shape[0]
 
         for i, (image1, image2) in enumerate(prefetch_to_device(batches, buffer_size=1, device=dev)):
-            out = self.predict_step((image1, image2)).as_subclass(torch.Tensor)
+            res = self.predict_step((image1, image2))
             cur = torch.cuda.current_stream(dev)
-            key = (i & 1, tuple(out.shape))
+            key = (i & 1, tuple(res.shape))
             if key not in pins:
-                pins[key] = torch.empty(out.shape, dtype=out.dtype).pin_memory()
+                pins[key] = torch.empty(res.shape, dtype=res.dtype).pin_memory()
             down.wait_stream(cur)
             with torch.cuda.stream(down):
+                out = res.as_subclass(torch.Tensor)      # pipelined forward: `down`, not the compute stream, waits for the loop
                 pins[key].copy_(out, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(down)
@@ -472,8 +547,9 @@ class RAFT:
             cnet = cnet.as_subclass(torch.Tensor)
             if self.drop_rate:     # extractor.py:109-111, 127-128: Dropout on the encoder outputs while training
                 # mask seeds: a different stream per data-parallel rank (ranks see different shards), per model seed and per
-                # optimizer step -- optimizer.iterations is part of a checkpoint, so a resumed run continues the sequence
-                # instead of replaying the masks from step 1
+                # optimizer step.  save_weights / load_weights persist the WEIGHTS only (as the reference's
+                # ModelCheckpoint(save_weights_only=True) does, train_sintel.py:104-107): a caller that resumes a run must restore
+                # optimizer.iterations itself, otherwise the mask sequence (and the LR schedule) restarts at step 1
                 step = int(getattr(getattr(self, 'optimizer', None), 'iterations', 0) or 0)
                 self._drop_step = max(getattr(self, '_drop_step', 0) + 1, step + 1)
                 base = _dropout_seed(getattr(self, 'seed', 0), _rank_of_this_process(), self._drop_step)
@@ -530,6 +606,7 @@ class RAFT:
                 mm, mv = wts[f'{name}/moving_mean'], wts[f'{name}/moving_variance']
                 mm.copy_(grad._axpby(self.BN_MOMENTUM, mm, 1.0 - self.BN_MOMENTUM, mean.contiguous()))
                 mv.copy_(grad._axpby(self.BN_MOMENTUM, mv, (1.0 - self.BN_MOMENTUM) * cnt / max(cnt - 1.0, 1.0), var.contiguous()))
+            grad.bump_pack_version()                     # parameters written outside the optimizer: packed copies are stale
         # the NumPy dictionary and the inference kernels' re-packed (Winograd-transformed, N-fused) copies are refreshed
         # lazily: by get_weights_dict / save_weights, and by the next forward call
         self._host_stale = True
