@@ -611,3 +611,39 @@ def test_dropout_seeds_differ_by_rank_model_seed_and_step():
                 seen.add(s + 1)
     assert len(seen) == 2 * 3 * 8 * 5
     assert _dropout_seed(3, 2, 10) == _dropout_seed(3, 2, 10)
+
+
+def test_pending_results_join_on_every_route_to_their_bytes():
+    """tf_raft_amd._dev.DeviceTensor of a pipelined forward call: every way to the data (torch functions and methods, tensors inside
+    lists / keyword arguments, data_ptr, as_subclass, numpy, np.asarray) joins the producer first; metadata reads do not.  (The
+    stream side is exercised on the GPU: tests/test_gpu_model.py::test_pending_results_join_whichever_stream_touches_them_first.)"""
+    from tf_raft_amd import _dev
+
+    class FakePending:
+        def __init__(self):
+            self.n = 0
+
+        def join(self):
+            self.n += 1
+
+    def fresh():
+        p = FakePending()
+        return _dev.wrap(torch.arange(12, dtype=torch.float32).reshape(3, 4), p), p
+
+    t, p = fresh()
+    assert (tuple(t.shape), t.dtype, t.device.type, t.ndim, t.is_cuda, t.requires_grad) == ((3, 4), torch.float32, 'cpu', 2, False, False)
+    assert p.n == 0                                            # metadata: no ordering needed
+    for touch in (lambda x: x.data_ptr(), lambda x: x[0], lambda x: x + 1, lambda x: torch.cat([x, x]), lambda x: x.sum(),
+                  lambda x: torch.add(torch.zeros(3, 4), other=x), lambda x: x.as_subclass(torch.Tensor), lambda x: x.numpy(),
+                  lambda x: np.asarray(x), lambda x: x.detach(), lambda x: x.contiguous(), lambda x: _dev.to_device.__wrapped__(x)
+                  if hasattr(_dev.to_device, '__wrapped__') else x.clone(), lambda x: _dev.join(x), lambda x: x.__cuda_array_interface__
+                  if x.is_cuda else x.tolist()):
+        t, p = fresh()
+        touch(t)
+        assert p.n >= 1, touch
+    t, p = fresh()
+    view = t[1]                                                # a derived tensor is ordinary: the join has happened already
+    assert isinstance(view, _dev.DeviceTensor) and view.__dict__.get('_pending') is None
+    plain = _dev.wrap(torch.zeros(2))                          # results of the serial path carry no Pending
+    assert plain.__dict__.get('_pending') is None and float((plain + 1).sum()) == 2.0
+    assert _dev.join([plain, torch.zeros(1), None]) is not None

@@ -26,4 +26,9 @@ _ffi.set_option('RAFT_LOOKUP_FUSED', 0)          # then the two-kernel loops: 14
 _ffi.set_option('RAFT_MASK_FUSED', 0)            # (mask.2 and the upsampling as their own kernels too)
 out = model([i1, i2])
 torch.cuda.synchronize()
+if len(sys.argv) > 3 and sys.argv[3] == 'probe':   # tools/instruction_mix.sh: the MFMA-only probe as the counters' calibration point
+    from tf_raft_amd import _dev
+    buf = torch.empty(512 * 256, device=dev)
+    _ffi.check(_dev.lib().raft_mfma_probe_f32(_dev.ptr(buf), 512, 256, _dev.stream_ptr()), 'mfma_probe')
+    torch.cuda.synchronize()
 print('done', float(out[-1].abs().max()))
