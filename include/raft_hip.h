@@ -36,20 +36,15 @@
  *   RAFT_GRU_WINO4      the same mask for F(4,5), preferred where both bits are set              (default 15)
  *   RAFT_WINO_TNW       1/2  32- or 64-channel workgroups of the Winograd kernels                (default: by grid size)
  *   RAFT_WINO_SB        0/1  pinned weight prefetch of the F(2x2,3x3) kernel                      (default: by grid size)
- *   RAFT_WINO_CK        1/2  16 or 32 channels per barrier (4: 64, split-K kernel only)          (default: by grid size)
  *   RAFT_WINO1D_TM      1/2  half- / full-height F(2,5) tiles                                    (default: by grid size)
+ *   RAFT_WINO_CK        1/2  16 or 32 channels per barrier (4: 64, split-K kernel only)          (default: by grid size)
  *   RAFT_WINO_KS        1/2  F(2x2,3x3) kernel: K split between two wave sets of a 512-thread workgroup (default: 2 for
  *                            launches of fewer wave-tasks than SIMDs, i.e. single pairs)
- *   RAFT_ENC_TILE       "<th><tn>" halo tile of the encoder convolutions, e.g. 72                (default: by map height)
  *   RAFT_ENC_WINO       0/1  encoder ResBlock 3x3 layers on the F(2x2,3x3) kernel                 (default 1)
  *   RAFT_ENC_WINO4      bit mask {1 layer1, 2 layer2, 4 layer3}: stride-1 3x3 layers of those encoder stages on the
  *                       F(4x4,3x3) kernel where a transformed copy is present (block_w44)      (default: every layer whose launch has more than 256 workgroups)
  *   RAFT_LOOKUP_FUSED   0/1  prediction loops: lookup + convc1 as two kernels / fused (raft_lookup_convc1_f32)  (default 1)
  *   RAFT_MASK_FUSED     0/1  prediction loops: mask.2 + convex upsampling as two kernels / one (the mask is never stored) (default: 1 from 2 pairs at 448x512 on)
- *   RAFT_LOOP_ROTATE    0/1  three-stream all-predictions loop with the fused mask kernel: two event operations per iteration on
- *                            the main stream instead of four ([fh1 | mask.0] and the mask branch's flow alternate between two buffers) (default 1)
- *   RAFT_MASK_BG_WGS    workgroups of the mask + upsampling kernel in the three-stream loop's iterations 0 .. n-2 (each walks
- *                       several tiles; 0 = one workgroup per tile)     (default 32; 0 where the chain's launches fill all CUs exactly)
  *   RAFT_CONVC2_KS      1/2  convc2 on the F(4x4) kernel in the loops: 8-row workgroups / K-split 4-row workgroups   (default: by grid size)
  *   RAFT_CONVF2_KS      1/2  the same for convf2                             (default: K-split below 56 eight-row workgroups)
  *   RAFT_EVENT_FENCE    0/1  cross-stream events of a raft_loop_ctx without / with the system-scope fence of a default HIP event
@@ -57,7 +52,6 @@
  *                            only order streams of one device; +0.4 .. 0.9 %, profiles/r10c_event_fence.txt)
  *   RAFT_CORR_XCD       0/1/n  volume build: plain (n, m, batch) tile grid / one region of the tile plane per XCD, walked in strips
  *                            of 2 (n >= 2: n) column tiles                                          (default 1)
- *   RAFT_LOOKUP_STAGED  0/1  strip kernel: direct strip stores / rows staged through LDS          (default 1)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)
  *   RAFT_LOOP_GRAPH     0/1  three-stream loops replayed as one hipGraph launch                  (default 0: measured
  *                       slower than stream launches on ROCm 7.2 at every batch size)

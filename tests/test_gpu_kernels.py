@@ -125,11 +125,11 @@ def _device_corr_with_oracle_pyramid(f1, f2, levels, radius):
     return dev, ref
 
 
-@pytest.mark.parametrize('staged', ['0', '1'])   # strip kernel: direct stores / rows transposed through LDS
 @pytest.mark.parametrize('radius,shape', [(4, (2, 8, 12, 64)), (3, (1, 16, 24, 32)), (4, (1, 56, 64, 32)),
                                           (4, (1, 14, 20, 32))])
-def test_corr_lookup_bit_exact_vs_oracle(rng, radius, shape, staged, raft_opt):
-    raft_opt.set('RAFT_LOOKUP_STAGED', staged)
+def test_corr_lookup_bit_exact_vs_oracle(rng, radius, shape):
+    """Strip kernel with the rows transposed through LDS (4 levels, aligned output: what every model runs); the direct-store
+    variant it falls back to otherwise is test_corr_lookup_three_levels."""
     B, h, w, C = shape
     f1 = rng.normal(size=shape).astype(np.float32)
     f2 = rng.normal(size=shape).astype(np.float32)

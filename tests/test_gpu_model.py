@@ -770,18 +770,17 @@ def test_three_stream_loop_is_bitwise_the_single_stream_loop():
 
 @pytest.mark.parametrize('shape,iters', [((2, 128, 192), 9), ((4, 448, 512), 5), ((1, 72, 104), 3)])
 def test_rotating_buffer_loop_is_bitwise_the_single_stream_loop(shape, iters, raft_opt):
-    """RAFT_LOOP_ROTATE (default on): the three-stream loop keeps two event operations per iteration on the main stream -- the
-    mask branch's inputs alternate between two buffers and its completion is awaited by the flow branch two iterations later.
+    """The three-stream loop with the fused mask kernel keeps two event operations per iteration on the main stream -- the mask
+    branch's inputs alternate between two buffers and its completion is awaited by the flow branch two iterations later.
     Odd and even iteration counts, repeated calls (a race would show as a changed bit), the benchmarked shape; against the
-    single-stream loop and against the four-event schedule."""
+    single-stream loop."""
     import tf_raft_amd
     B, H, W = shape
     i1, i2, wts = _conditioned_case('raft', H, W, 2, B=B)
     raft_opt.set('RAFT_MASK_FUSED', '1')          # the schedule belongs to the fused mask kernel (default from 2 pairs on)
     ref = [_np(p) for p in tf_raft_amd.RAFT(weights=wts, iters_pred=iters, overlap=False)([i1, i2])]
-    for opt in ('1', '0'):
-        raft_opt.set('RAFT_LOOP_ROTATE', opt)
-        model = tf_raft_amd.RAFT(weights=wts, iters_pred=iters, overlap=True)
+    for pipeline in (False, True):
+        model = tf_raft_amd.RAFT(weights=wts, iters_pred=iters, overlap=True, pipeline=pipeline)
         for _ in range(4):
             got = [_np(p) for p in model([i1, i2])]
             for a, b_ in zip(got, ref):

@@ -66,9 +66,9 @@ __host__ __device__ inline void raft_untiled_yx(int n, int tiles_x, int *y, int 
 // calls getenv.  raft_opt(id, dflt) = the switch's value, or dflt while it is unset.
 enum RaftOptionId {
     RAFT_OPT_CONV_WINO, RAFT_OPT_SMALL_WINO, RAFT_OPT_GRU_WINO, RAFT_OPT_GRU_WINO4, RAFT_OPT_WINO_TNW, RAFT_OPT_WINO_SB,
-    RAFT_OPT_WINO_CK, RAFT_OPT_WINO1D_TM, RAFT_OPT_LOOKUP_STAGED,
-    RAFT_OPT_LOOKUP_FUSED, RAFT_OPT_ONDEMAND_BLOCK, RAFT_OPT_ENC_TILE, RAFT_OPT_ENC_WINO, RAFT_OPT_LOOP_GRAPH,
-    RAFT_OPT_WINO_KS, RAFT_OPT_CONV_WINO4, RAFT_OPT_WINO4_KS, RAFT_OPT_MASK_FUSED, RAFT_OPT_ENC_WINO4, RAFT_OPT_LOOP_ROTATE, RAFT_OPT_MASK_BG_WGS, RAFT_OPT_CONVC2_KS, RAFT_OPT_CONVF2_KS,
+    RAFT_OPT_WINO_CK, RAFT_OPT_WINO1D_TM,
+    RAFT_OPT_LOOKUP_FUSED, RAFT_OPT_ONDEMAND_BLOCK, RAFT_OPT_ENC_WINO, RAFT_OPT_LOOP_GRAPH,
+    RAFT_OPT_WINO_KS, RAFT_OPT_CONV_WINO4, RAFT_OPT_WINO4_KS, RAFT_OPT_MASK_FUSED, RAFT_OPT_ENC_WINO4, RAFT_OPT_CONVC2_KS, RAFT_OPT_CONVF2_KS,
     RAFT_OPT_EVENT_FENCE, RAFT_OPT_CORR_XCD,
     RAFT_OPT_COUNT
 };

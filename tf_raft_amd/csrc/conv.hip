@@ -931,7 +931,7 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
     ov.e_up = ctx->ev[3];
     ov.e_rot[0] = ctx->ev[2];   // e_fm is not used in that mode
     ov.e_rot[1] = ctx->ev[3];
-    ov.rot = !final_only && mask_is_fused(wts, (int64_t)B * h * w) && raft_opt(RAFT_OPT_LOOP_ROTATE, 1) != 0;
+    ov.rot = !final_only && mask_is_fused(wts, (int64_t)B * h * w);
     const int64_t up = (int64_t)B * 64 * h * w * 2;
     int rc = (int)hipEventRecord(ov.e_fh, s);   // state prepared on `stream`: the flow branch may start
     for (int i = 0; i < iters && rc == RAFT_OK; ++i) {
@@ -945,7 +945,7 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
         // 256: a single 1024 x 1024 pair loses 6 % to a background branch); one process, profiles/r09d_mask_bg_shapes.txt:
         // 448 x 512 at 4 / 5 / 6 / 8 / 12 / 16 pairs +2.7 / +7.9 / +4.5 / +6.1 / +2.5 / +1.6 %, 16 or 40+ workgroups lose
         const int head_grid = B * ((h + 7) / 8) * ((w + 63) / 64) * 8;
-        ov.mask_bg_wgs = (ov.rot && i + 1 < iters) ? raft_opt(RAFT_OPT_MASK_BG_WGS, head_grid % 256 ? 32 : 0) : 0;
+        ov.mask_bg_wgs = (ov.rot && i + 1 < iters) ? (head_grid % 256 ? 32 : 0) : 0;
         if (rc == RAFT_OK) rc = update_basic_impl(wts, B, h, w, st, stream, nullptr, &ov, with_mask, fused ? &src : nullptr, mf ? up_i : nullptr);
         if (!with_mask) continue;
         if (!mf) {

@@ -588,8 +588,8 @@ extern "C" int raft_corr_lookup_f32(const float *pyr, const int64_t *level_offse
     a.nq = (int64_t)B * h * w;
     a.ld_out = ld_out;
     hipStream_t s = (hipStream_t)stream;
-    // A/B timing switch only: 0 = direct strip stores
-    const bool staged = raft_opt(RAFT_OPT_LOOKUP_STAGED, 1) != 0 && levels == 4 && (ld_out & 3) == 0 && raft_aligned16(out);
+    // rows staged through LDS and written as 16-byte stores wherever the output allows it, direct strip stores otherwise
+    const bool staged = levels == 4 && (ld_out & 3) == 0 && raft_aligned16(out);
     if (radius == 4)
         launch_lookup<4>(a, staged, s);
     else if (radius == 3)

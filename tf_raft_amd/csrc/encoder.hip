@@ -165,13 +165,7 @@ int enc_conv(const ConvArgs &a, EncKind kind, int epi, int th, int tn, hipStream
 void enc_pick(int H, int npad, int *th, int *tn) {
     *th = (H % 7 == 0) ? 7 : 8;
     *tn = 1;
-    if (raft_opt_is_set(RAFT_OPT_ENC_TILE)) {   // tuning override "<th><tn>", e.g. 72 (raft_set_option)
-        const int v = raft_opt(RAFT_OPT_ENC_TILE, 0), t = v / 10, n = v % 10;
-        if ((t == 7 || t == 8) && (n == 1 || n == 2) && npad % (64 * n) == 0) {
-            *th = t;
-            *tn = n;
-        }
-    }
+    (void)npad;
 }
 
 void same_pad(int in, int k, int stride, int *out, int *before) {

@@ -55,9 +55,9 @@ extern "C" uint32_t raft_crc32c(uint32_t crc, const void *data, size_t n) {
 namespace {
 const char *const kOptNames[RAFT_OPT_COUNT] = {
     "RAFT_CONV_WINO", "RAFT_SMALL_WINO", "RAFT_GRU_WINO", "RAFT_GRU_WINO4", "RAFT_WINO_TNW", "RAFT_WINO_SB",
-    "RAFT_WINO_CK", "RAFT_WINO1D_TM", "RAFT_LOOKUP_STAGED",
-    "RAFT_LOOKUP_FUSED", "RAFT_ONDEMAND_BLOCK", "RAFT_ENC_TILE", "RAFT_ENC_WINO", "RAFT_LOOP_GRAPH",
-    "RAFT_WINO_KS", "RAFT_CONV_WINO4", "RAFT_WINO4_KS", "RAFT_MASK_FUSED", "RAFT_ENC_WINO4", "RAFT_LOOP_ROTATE", "RAFT_MASK_BG_WGS", "RAFT_CONVC2_KS", "RAFT_CONVF2_KS",
+    "RAFT_WINO_CK", "RAFT_WINO1D_TM",
+    "RAFT_LOOKUP_FUSED", "RAFT_ONDEMAND_BLOCK", "RAFT_ENC_WINO", "RAFT_LOOP_GRAPH",
+    "RAFT_WINO_KS", "RAFT_CONV_WINO4", "RAFT_WINO4_KS", "RAFT_MASK_FUSED", "RAFT_ENC_WINO4", "RAFT_CONVC2_KS", "RAFT_CONVF2_KS",
     "RAFT_EVENT_FENCE", "RAFT_CORR_XCD",
 };
 constexpr int kTileEntries = 16;

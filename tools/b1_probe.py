@@ -68,7 +68,7 @@ print(f'default                : {latency():.2f} ms')
 for name, opts in [('overlap off', None), ('WINO_TNW=2', {'RAFT_WINO_TNW': 2}), ('WINO_TNW=1', {'RAFT_WINO_TNW': 1}),
                    ('CONV_TILE=141', {'RAFT_CONV_TILE': 141}), ('CONV_TILE=171', {'RAFT_CONV_TILE': 171}),
                    ('WINO1D_TM=1', {'RAFT_WINO1D_TM': 1}), ('GRU_WINO4=0 (F(2,5))', {'RAFT_GRU_WINO4': 0}),
-                   ('ENC_TILE=71', {'RAFT_ENC_TILE': 71}), ('ENC_TILE=81', {'RAFT_ENC_TILE': 81})]:
+                   ]:
     if opts is None:
         model.overlap = False
         print(f'{name:23s}: {latency():.2f} ms')

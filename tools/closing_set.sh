@@ -7,6 +7,8 @@
 #   <tag>_single_stream_b{4,8}_rocprofv3_kernel_stats.csv + kernel_durations.json   single-stream loop, per-stage durations
 #   <tag>_pmc_per_kernel.csv + pmc_traffic.json     FETCH_SIZE / WRITE_SIZE passes at 8 pairs      (skipped with SKIP_PMC=1)
 #   <tag>_loop_timeline_b4.txt                      kernel timeline of the product loop
+#   <tag>_pipeline_ab.txt                           the bench step with RAFT_PIPELINE=0 / 1 (A/B/A/B)
+#   <tag>_instruction_mix.txt                       MFMA / VALU / LDS instructions per wave per kernel (tools/instruction_mix.sh)
 # usage: bash tools/closing_set.sh <tag>
 tag=${1:-r10a}
 export TMPDIR=/tmp
@@ -35,6 +37,14 @@ fi
 [ -f $out/${tag}_kernel_durations.json ] && cp $out/${tag}_kernel_durations.json profiles/kernel_durations.json
 [ -f $out/${tag}_pmc_traffic.json ] && cp $out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
 timeout 600 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_b4.log 2>&1
+# the serial schedule of consecutive calls beside the pipelined default (same box, same minute)
+for p in 0 1 0 1; do
+  RAFT_PIPELINE=$p timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity 2>/dev/null | python -c "
+import json, sys
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('RAFT_PIPELINE=$p value', d['value'], 'ms_per_step', d['ms_per_step'])"
+done > $out/${tag}_pipeline_ab.txt 2>&1
+[ -z "${SKIP_PMC:-}" ] && bash tools/instruction_mix.sh $tag 4 > /dev/null 2>&1 && rm -rf $out/${tag}_mix
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $out/${tag}_prof -o bench -- python $root/bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_b4_under_rocprof.log 2>&1
 f=$(ls $out/${tag}_prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_bench_b4_rocprofv3_kernel_stats.csv

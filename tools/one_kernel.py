@@ -1,7 +1,7 @@
 """Run ONE kernel configuration repeatedly (for rocprofv3 --pmc passes and A/B timing on the GPU box).
 
   python tools/one_kernel.py conv <layer> <tile|auto> [B] [reps]
-  python tools/one_kernel.py lookup <direct|staged> [B] [reps]
+  python tools/one_kernel.py lookup staged [B] [reps]
   python tools/one_kernel.py upsample [B] [reps]
 Prints the HIP-event average per launch.
 """
@@ -109,7 +109,7 @@ def main():
         ver = sys.argv[2]
         B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
         reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-        _ffi_opt("RAFT_LOOKUP_STAGED", "0" if ver in ("v3", "direct") else "1")
+        assert ver == 'staged', 'the direct-store variant is only the fallback for unaligned / 3-level outputs now'
         from tf_raft_amd.layers.corr import CorrBlock
         f1 = rng.normal(size=(B, H, W, 256)).astype(np.float32)
         f2 = rng.normal(size=(B, H, W, 256)).astype(np.float32)
