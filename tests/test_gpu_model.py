@@ -729,6 +729,29 @@ def test_pipelined_calls_are_bitwise_the_serial_calls(variant, kw, shape, iters)
         np.testing.assert_array_equal(other.cpu().numpy(), serial.predict_step(small_in).cpu().numpy())
 
 
+def test_weights_replaced_while_a_pipelined_call_is_in_flight():
+    """set_weights frees the packed device blobs of the old weights; a loop still in flight on the loop stream must be waited for
+    first (stream order does not cover it any more).  The in-flight call keeps the OLD weights' result, the next call has the new."""
+    import tf_raft_amd
+    from tf_raft_amd import weights as wm
+    w_a, w_b = wm.init_weights('raft', seed=11, perturb=True), wm.init_weights('raft', seed=12, perturb=True)
+    a, b = (torch.as_tensor(x).cuda() for x in _images(8, 2, 128, 192))
+    serial = tf_raft_amd.RAFT(weights=w_a, iters_pred=8, pipeline=False)
+    want_a = serial([a, b])[-1].cpu().numpy()
+    serial.set_weights(w_b)
+    want_b = serial([a, b])[-1].cpu().numpy()
+    model = tf_raft_amd.RAFT(weights=w_a, iters_pred=8, pipeline=True)
+    for _ in range(3):
+        model.set_weights(w_a)
+        out_a = model([a, b])
+        model.set_weights(w_b)                                   # while out_a's loop runs
+        junk = torch.full((1 << 24,), float('nan'), device='cuda')   # whatever the allocator hands out now must not be read by that loop
+        out_b = model([a, b])
+        np.testing.assert_array_equal(out_a[-1].cpu().numpy(), want_a)
+        np.testing.assert_array_equal(out_b[-1].cpu().numpy(), want_b)
+        del junk
+
+
 def test_pending_results_join_whichever_stream_touches_them_first():
     """A pipelined result waits for its loop on the stream that first touches its data -- a side stream here -- and metadata
     reads do not wait."""

@@ -111,6 +111,7 @@ class RAFT:
     # ---- weights ------------------------------------------------------------------------------
     def set_weights(self, weights: Dict[str, np.ndarray]) -> None:
         weights_mod.check_weights(self.variant, weights)
+        self._join_pipeline()                       # the old device blobs are freed below: no loop may still be reading them
         self._weights = dict(weights)
         self._inference_stale = False
         self._train_vars = None                     # train_step re-reads its device master copies
@@ -291,6 +292,7 @@ class RAFT:
         # model.py:70-71 (2 * (image / 255) - 1) is applied by the encoders while they stage the image
         if self.pipeline and self.overlap and not training:
             return self._forward_pipelined(image1, image2, final_only)
+        self._join_pipeline()                       # (a training-mode or serial call after pipelined ones)
         if self.overlap and not training:
             # the context encoder does not depend on the feature encoder or the volume: it runs on a side stream
             # next to them (its one-workgroup-per-CU layers fill the tails of the feature encoder's launches)
@@ -356,6 +358,14 @@ class RAFT:
     # cannot hand them out before the loop has finished, and loops of consecutive calls follow each other in stream order.
     # Per-call results are bit-identical to the serial schedule (same kernels, same order per call):
     # tests/test_gpu_model.py::test_pipelined_calls_are_bitwise_the_serial_calls.
+    def _join_pipeline(self):
+        """Make the current stream wait for every loop this model still has in flight: called before anything that frees or
+        rewrites buffers a loop reads (weight blobs, training's in-place optimizer updates) -- in the serial schedule stream order
+        gave that for free."""
+        for ent in getattr(self, '_ring', ()):
+            if ent is not None and ent[1] is not None:
+                torch.cuda.current_stream(ent[0].net.device).wait_event(ent[1])
+
     def _ring_state(self, slot, B, h, w, device):
         ent = self._ring[slot]
         if ent is None or (ent[0].B, ent[0].h, ent[0].w) != (B, h, w) or ent[0].net.device != device:
@@ -513,6 +523,7 @@ class RAFT:
             raise RuntimeError('call compile() before train_step()')
         if self.loss is not losses.sequence_loss:
             raise NotImplementedError('train_step differentiates tf_raft_amd.losses.sequence_loss only')
+        self._join_pipeline()                       # inference loops still in flight read the weights this step updates in place
         if self.optimizer is None or not hasattr(self.optimizer, 'apply_gradients'):
             raise RuntimeError('compile() needs an optimizer with apply_gradients(grads, variables, clip_norm) '
                                '(tf_raft_amd.training.AdamW)')

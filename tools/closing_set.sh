@@ -1,7 +1,7 @@
 #!/bin/bash
 # Closing set of a state of the tree (GPU box, repo root).  Everything bench.py's evidence fields point to is regenerated here
 # from the library that is loaded in the same call:
-#   <tag>_pytest_gpu.log, <tag>_smoke.log          the GPU suite and smoke()                      (skipped with SKIP_TESTS=1)
+#   <tag>_pytest_gpu.log, <tag>_smoke.log, <tag>_parity_tests.log   the GPU suite, smoke(), the model parity tests with their errors (skipped with SKIP_TESTS=1)
 #   <tag>_bench_b4.log                              the default bench line (BASELINE configs[1])
 #   <tag>_bench_b4_rocprofv3_kernel_stats.csv       rocprofv3 --kernel-trace --stats of the same command (product loop)
 #   <tag>_single_stream_b{4,8}_rocprofv3_kernel_stats.csv + kernel_durations.json   single-stream loop, per-stage durations
@@ -19,6 +19,8 @@ cd $root
 if [ -z "${SKIP_TESTS:-}" ]; then
   timeout 1800 python -m pytest tests -m gpu -q -x > $out/${tag}_pytest_gpu.log 2>&1; echo "rc=$?" >> $out/${tag}_pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/${tag}_smoke.log 2>&1; echo "rc=$?" >> $out/${tag}_smoke.log
+  # the parity tests once more with their measured errors on stdout
+  timeout 900 python -m pytest tests/test_gpu_model.py -q -s -k "north_star or jump_regime or mid_regime or pipelined or pending or weights_replaced" 2>&1 | grep -E "^\[parity\]|passed|failed" > $out/${tag}_parity_tests.log
 fi
 cd /tmp
 for b in 4 8 16; do
