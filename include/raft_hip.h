@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 216          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 217          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -403,6 +403,11 @@ int64_t raft_encoder_workspace_floats(const raft_encoder_weights *w, int n, int 
  * 2 * (image / 255) - 1 (reference model.py:70-71) while the image is staged. */
 int raft_encoder_f32(const raft_encoder_weights *w, const float *images, int n, int H, int W,
                      int input_affine, float *out, float *workspace, void *stream);
+/* The feature encoder's call on [image1, image2] (reference extractor.py:114-116 concatenates along the batch, 128-130 splits
+ * again): images_a / images_b: (n_each, H, W, 3) each, staged from where they lie; out: (2 * n_each, ...), the first n_each
+ * maps belong to images_a.  Workspace = raft_encoder_workspace_floats(w, 2 * n_each, H, W). */
+int raft_encoder_pair_f32(const raft_encoder_weights *w, const float *images_a, const float *images_b, int n_each, int H, int W,
+                          int input_affine, float *out, float *workspace, void *stream);
 
 /* ------------------------------------------------------------------ SmallRAFT update block */
 

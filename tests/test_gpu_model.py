@@ -131,6 +131,21 @@ def dataset_arrays(a, b):
         yield a[i:i + 1], b[i:i + 1]
 
 
+def test_encoder_pair_is_bitwise_the_concatenated_batch():
+    """fnet([image1, image2]) stages the two tensors where they lie (raft_encoder_pair_f32) instead of concatenating them
+    (reference extractor.py:114-116): the feature maps are bit for bit those of the concatenated batch."""
+    import tf_raft_amd
+    for cls, shape in ((tf_raft_amd.RAFT, (3, 72, 104)), (tf_raft_amd.SmallRAFT, (2, 64, 96))):
+        model = cls(iters_pred=1)
+        a, b = (torch.as_tensor(x).cuda() for x in _images(17, *shape))
+        f1, f2 = model.fnet([a, b], _raw_images=True)
+        both = model.fnet(torch.cat([a, b], dim=0), _raw_images=True)
+        np.testing.assert_array_equal(_np(f1), _np(both[:shape[0]]))
+        np.testing.assert_array_equal(_np(f2), _np(both[shape[0]:]))
+    with pytest.raises(ValueError):
+        model.fnet([a, b[:1]])
+
+
 def test_hip_loop_is_deterministic():
     """Same feature maps, same state -> bit-identical predictions from two runs of the HIP loop."""
     import tf_raft_amd

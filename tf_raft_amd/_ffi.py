@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 216     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 217     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -137,6 +137,7 @@ _SIGNATURES = {
                                           C.POINTER(State), _P, _P, C.POINTER(C.c_float)]),
     'raft_encoder_workspace_floats': (C.c_int64, [C.POINTER(EncoderWeights), _I, _I, _I]),
     'raft_encoder_f32': (_I, [C.POINTER(EncoderWeights), _P, _I, _I, _I, _I, _P, _P, _P]),
+    'raft_encoder_pair_f32': (_I, [C.POINTER(EncoderWeights), _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'raft_small_update_workspace_floats': (C.c_int64, [_I, _I, _I]),
     'raft_prepare_state_small_f32': (_I, [_P, _I, _I, _I, C.POINTER(State), _P]),
     'raft_update_small_f32': (_I, [C.POINTER(SmallUpdateWeights), _I, _I, _I, C.POINTER(State), _P]),

@@ -22,11 +22,14 @@ int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide
 namespace {
 
 // ---------------------------------------------------------------- small kernels
-__global__ void __launch_bounds__(256) enc_prep_kernel(const float *__restrict__ img, f32x4 *__restrict__ out,
-                                                       int64_t npix, int affine) {
+// pixels [0, npix_a) come from img, the rest from img_b (the feature encoder's [image1, image2] batch: extractor.py:114-116
+// concatenates them; here they are staged from where they lie)
+__global__ void __launch_bounds__(256) enc_prep_kernel(const float *__restrict__ img, const float *__restrict__ img_b,
+                                                       int64_t npix_a, f32x4 *__restrict__ out, int64_t npix, int affine) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
-    float r = img[3 * i], g = img[3 * i + 1], b = img[3 * i + 2];
+    const float *src = i < npix_a ? img + 3 * i : img_b + 3 * (i - npix_a);
+    float r = src[0], g = src[1], b = src[2];
     if (affine) {   // reference model.py:70-71: 2 * (image / 255) - 1, same operation order
 #pragma clang fp contract(off)
         r = 2.f * (r / 255.f) - 1.f;
@@ -198,8 +201,23 @@ extern "C" int64_t raft_encoder_workspace_floats(const raft_encoder_weights *w, 
     return align4((int64_t)n * H * W * 4) + 5 * act + part + ss;
 }
 
+static int encoder_impl(const raft_encoder_weights *w, const float *images, const float *images_b, int n_a, int n, int H, int W,
+                        int input_affine, float *out, float *workspace, void *stream);
+
 extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *images, int n, int H, int W,
                                 int input_affine, float *out, float *workspace, void *stream) {
+    return encoder_impl(w, images, images, n, n, H, W, input_affine, out, workspace, stream);
+}
+
+extern "C" int raft_encoder_pair_f32(const raft_encoder_weights *w, const float *images_a, const float *images_b, int n_each,
+                                     int H, int W, int input_affine, float *out, float *workspace, void *stream) {
+    RAFT_REQUIRE_PTR(images_b);
+    RAFT_REQUIRE(n_each > 0, RAFT_E_SHAPE);
+    return encoder_impl(w, images_a, images_b, n_each, 2 * n_each, H, W, input_affine, out, workspace, stream);
+}
+
+static int encoder_impl(const raft_encoder_weights *w, const float *images, const float *images_b, int n_a, int n, int H, int W,
+                        int input_affine, float *out, float *workspace, void *stream) {
     RAFT_REQUIRE_PTR(w);
     RAFT_REQUIRE_PTR(images);
     RAFT_REQUIRE_PTR(out);
@@ -253,7 +271,7 @@ extern "C" int raft_encoder_f32(const raft_encoder_weights *w, const float *imag
 
     {   // image -> 4-channel padded (and normalised) image
         const int64_t npix = (int64_t)n * H * W;
-        enc_prep_kernel<<<raft_ceil_div(npix, 256), 256, 0, s>>>(images, (f32x4 *)b.img4, npix, input_affine);
+        enc_prep_kernel<<<raft_ceil_div(npix, 256), 256, 0, s>>>(images, images_b, (int64_t)n_a * H * W, (f32x4 *)b.img4, npix, input_affine);
         RAFT_TRY(raft_launch_status());
     }
 

@@ -121,12 +121,17 @@ class _Encoder:
         self.c = c
         self._ws = None
 
-    def forward_device(self, images: torch.Tensor, input_affine: bool = False) -> torch.Tensor:
+    def forward_device(self, images: torch.Tensor, input_affine: bool = False, images_b: torch.Tensor = None) -> torch.Tensor:
         """(n, H, W, 3) device tensor -> (n, ceil(H/8), ceil(W/8), output_dim) through ``raft_encoder_f32``.
-        ``input_affine`` applies the model's ``2 * (image / 255) - 1`` while staging (model.py:70-71)."""
+        ``input_affine`` applies the model's ``2 * (image / 255) - 1`` while staging (model.py:70-71).  With ``images_b`` (same
+        shape) the batch is [images | images_b] (extractor.py:114-116), staged from the two tensors without a concatenation."""
         n, H, W, ch = images.shape
         if ch != 3:
             raise ValueError(f'images must be (n, H, W, 3), got {tuple(images.shape)}')
+        if images_b is not None:
+            if images_b.shape != images.shape:
+                raise ValueError(f'image batches differ: {tuple(images.shape)} / {tuple(images_b.shape)}')
+            n = 2 * n
         lib = _dev.lib()
         need = lib.raft_encoder_workspace_floats(C.byref(self.c), n, H, W)
         if need <= 0:
@@ -137,8 +142,12 @@ class _Encoder:
         for _ in range(3):
             ho, wo = (ho + 1) // 2, (wo + 1) // 2
         out = torch.empty((n, ho, wo, self.output_dim), device=images.device, dtype=torch.float32)
-        check(lib.raft_encoder_f32(C.byref(self.c), _dev.ptr(images), n, H, W, 1 if input_affine else 0,
-                                   _dev.ptr(out), _dev.ptr(self._ws), _dev.stream_ptr()), 'encoder')
+        if images_b is not None:
+            check(lib.raft_encoder_pair_f32(C.byref(self.c), _dev.ptr(images), _dev.ptr(images_b), n // 2, H, W, 1 if input_affine else 0,
+                                            _dev.ptr(out), _dev.ptr(self._ws), _dev.stream_ptr()), 'encoder_pair')
+        else:
+            check(lib.raft_encoder_f32(C.byref(self.c), _dev.ptr(images), n, H, W, 1 if input_affine else 0,
+                                       _dev.ptr(out), _dev.ptr(self._ws), _dev.stream_ptr()), 'encoder')
         return out
 
     # ---- building blocks ----------------------------------------------------------------------
@@ -177,6 +186,11 @@ class _Encoder:
         """reference extractor.py:113-130 / 158-175.  NHWC in, NHWC out; a list input is
         concatenated along the batch and split again."""
         is_list = isinstance(inputs, (tuple, list))
+        if is_list and not training and len(inputs) == 2:
+            a, b = (_dev.to_device(i) for i in inputs)
+            y = self.forward_device(a, input_affine=bool(_raw_images), images_b=b)      # no concatenation: staged from both tensors
+            half = y.shape[0] // 2
+            return [_dev.wrap(y[:half]), _dev.wrap(y[half:])]
         if is_list:
             x = torch.cat([_dev.to_device(i) for i in inputs], dim=0)
         else:
