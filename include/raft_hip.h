@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 217          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 218          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -476,6 +476,16 @@ int raft_corr_lookup_backward_f32(const float *pyr, const int64_t *level_offsets
 
 /* dx = dy where y > 0 else 0 (the relu between the convolutions of the update block), n elements. */
 int raft_relu_backward_f32(const float *y, const float *dy, float *dx, int64_t n, void *stream);
+
+/* Training-time weight packing on the device (train_step's master weights change every step: reference model.py:134-136), one
+ * launch per (kernel, use).  kernel: (kh, kw, cin, cout) Keras layout.  dgrad != 0 packs the kernel of the INPUT gradient
+ * K'[ky][kx][co][ci] = K[kh-1-ky][kw-1-kx][ci][co] instead.  mode 0: the kh * kw taps as they are; mode 1 (3x3): the 16 taps
+ * G g G^T of F(2x2, 3x3), g = (4, 3) row-major doubles; mode 2 (1x5 / 5x1): the gt taps G' g of F(gt - 4, 5), g = (gt, 5) doubles;
+ * float64 accumulation, one rounding.  wp: [taps][kpad / 4][npad][4] as raft_conv2d_f32 / raft_conv2d_winograd_f32 /
+ * raft_conv1d_winograd{,4}_f32 consume it (zero beyond the kernel's channels); bias_out: npad floats (bias, or zeros when bias is
+ * NULL or dgrad is set). */
+int raft_pack_train_conv_f32(const float *kernel, const float *bias, int kh, int kw, int cin, int cout, int dgrad, int mode,
+                             const double *g, int gt, int kpad, int npad, float *wp, float *bias_out, void *stream);
 
 /* Keras Conv2D (stride 1, 'same'; kh x kw in {1x1, 3x3, 1x5, 5x1}) backward w.r.t. kernel and bias:
  *   d_kernel[ky][kx][ci][co] = sum_pixels x[b, y + ky - (kh-1)/2, x + kx - (kw-1)/2, ci] * dy[b, y, x, co]   (Keras layout)

@@ -863,3 +863,33 @@ def test_train_step_runs_device_resident_with_dropout_and_bf16_tape(rng):
     out = model([data[0], data[1]])                                               # inference re-packs from the trained weights
     assert np.isfinite(_np(out[-1])).all()
     report('train_step device-resident, dropout 0.1, bf16 tape', loss1=float(r1['loss']), loss2=float(r2['loss']), tensors_moved=len(moved))
+
+
+@pytest.mark.parametrize('ksize,cin,cout', [((3, 3), 128, 64), ((3, 3), 36, 100), ((1, 5), 256, 128), ((5, 1), 40, 256), ((1, 1), 352, 256),
+                                            ((7, 7), 4, 64)])
+@pytest.mark.parametrize('dgrad', [False, True])
+def test_fused_training_pack_equals_the_tensor_op_chain(rng, ksize, cin, cout, dgrad):
+    """raft_pack_train_conv_f32 (one launch: optional flip / transpose for the input gradient, optional Winograd transform in
+    float64, zero-padded operand layout) against the chain of torch ops it replaces, for a DEVICE kernel: direct layout, F(2x2, 3x3)
+    and F(4, 5).  Same float64 arithmetic, possibly another summation order: equal to one fp32 ulp."""
+    from tf_raft_amd import grad, packing
+    kh, kw = ksize
+    if dgrad and kh % 2 == 0:
+        pytest.skip('input-gradient kernels are odd-sized')
+    kernel = torch.as_tensor(rng.normal(size=(kh, kw, cin, cout)).astype(np.float32)).cuda()
+    bias = torch.as_tensor(rng.normal(size=(cout,)).astype(np.float32)).cuda()
+    k_ch = cout if dgrad else cin
+    cpad = packing.round_up(k_ch, 32)
+    for wino in (None, {(3, 3): '2d', (1, 5): '1d', (5, 1): '1d'}.get(ksize)):
+        if wino is None and ksize in ((3, 3), (1, 5), (5, 1)) and cin == 36:
+            continue
+        kd = grad._dgrad_kernel_any(kernel) if dgrad else kernel
+        want_wp, want_b, want_npad = grad._pack_conv_any(grad._wino_transform_any(kd) if wino else kd, None if dgrad else bias, [(k_ch, cpad)])
+        got_wp, got_b, got_npad = grad._pack_train_device(kernel, bias, wino, dgrad, cpad)
+        assert got_npad == want_npad and tuple(got_wp.shape) == tuple(want_wp.shape)
+        np.testing.assert_allclose(got_wp.cpu().numpy(), want_wp.cpu().numpy(), rtol=2.5e-7, atol=1e-9)
+        np.testing.assert_array_equal(got_b.cpu().numpy(), want_b.cpu().numpy())
+        if wino is None:
+            np.testing.assert_array_equal(got_wp.cpu().numpy(), want_wp.cpu().numpy())          # pure data movement: bit-equal
+        if ksize not in ((3, 3), (1, 5), (5, 1)):
+            break

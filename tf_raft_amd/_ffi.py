@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 217     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 218     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -82,6 +82,7 @@ _SIGNATURES = {
     'raft_sequence_loss_grad_f32': (_I, [_P, _P, _P, C.c_int64, _I, C.c_int64, C.c_double, C.c_float, C.c_float, _P, _P]),
     'raft_corr_lookup_backward_f32': (_I, [_P, c_i64_p, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'raft_relu_backward_f32': (_I, [_P, _P, _P, C.c_int64, _P]),
+    'raft_pack_train_conv_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _I, _I, _I, _P, _P, _P]),
     'raft_conv2d_wgrad_workspace_floats': (C.c_int64, [_I, _I, _I, _I, _I, _I, _I]),
     'raft_conv2d_wgrad_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'raft_conv2d_wgrad_multi_f32': (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

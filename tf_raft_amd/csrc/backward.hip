@@ -1438,3 +1438,84 @@ extern "C" int raft_dropout_backward_f32(const float *dy, const unsigned char *m
     dropout_backward_kernel<<<raft_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(dy, mask, n, 1.0f / (1.0f - rate), dx);
     return raft_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Training-time weight packing on the device, ONE launch per (kernel, use): the master weights live on the device and change
+// every step, and repacking them with tensor-library ops was ~10 small kernels per layer and use (zero-fills, slice copies, casts,
+// an einsum, a transposing copy: ~1200 launches = 7 ms of a 55 ms step, profiles/r11p_train_step_trace.txt).
+//   kernel (kh, kw, cin, cout) Keras layout, fp32;  dgrad: use K'[ky][kx][co][ci] = K[kh-1-ky][kw-1-kx][ci][co] instead
+//   mode 0: taps = kh * kw, U = K';  mode 1 (3x3): taps = 16, U[a][b] = sum_uv G[a][u] G[b][v] K'[u][v];  mode 2 (1x5 / 5x1):
+//   taps = gt, U[t] = sum_j G[t][j] K'[j]  -- float64 accumulation, ONE rounding (packing.winograd_kernel / winograd1d_kernel)
+//   wp[t][k / 4][n][k % 4] = U[t][k][n] for k < K, n < N, else 0  (K, N = cin, cout; swapped for dgrad); bias_out[n] = bias[n] or 0
+// ------------------------------------------------------------------------------------------------
+struct PackTrainArgs {
+    const float *kernel, *bias;
+    float *wp, *bias_out;
+    int kh, kw, cin, cout, dgrad, mode, gt, kpad, npad;
+    double g[40];   // mode 1: G (4 x 3); mode 2: G (gt x 5); row-major
+};
+__global__ void __launch_bounds__(256) pack_train_kernel(PackTrainArgs p) {
+    const int taps = p.mode == 0 ? p.kh * p.kw : (p.mode == 1 ? 16 : p.gt);
+    const int64_t total = (int64_t)taps * p.kpad * p.npad;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < p.npad) p.bias_out[i] = (p.bias != nullptr && !p.dgrad && i < p.cout) ? p.bias[i] : 0.f;
+    if (i >= total) return;
+    // i = ((t * kpad/4 + k4) * npad + n) * 4 + e : consecutive threads write consecutive floats of wp
+    const int e = (int)(i & 3);
+    const int64_t q = i >> 2;
+    const int n = (int)(q % p.npad);
+    const int64_t r = q / p.npad;
+    const int k4 = (int)(r % (p.kpad >> 2)), t = (int)(r / (p.kpad >> 2));
+    const int k = 4 * k4 + e;
+    const int K = p.dgrad ? p.cout : p.cin, N = p.dgrad ? p.cin : p.cout;
+    float v = 0.f;
+    if (k < K && n < N) {
+        auto src = [&](int ky, int kx) -> double {   // K'[ky][kx][k][n]
+            if (p.dgrad) return (double)p.kernel[(((int64_t)(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)) * p.cin + n) * p.cout + k];
+            return (double)p.kernel[(((int64_t)ky * p.kw + kx) * p.cin + k) * p.cout + n];
+        };
+        if (p.mode == 0) {
+            v = (float)src(t / p.kw, t % p.kw);
+        } else if (p.mode == 1) {
+            const int a = t >> 2, b = t & 3;
+            double acc = 0.0;
+            for (int u = 0; u < 3; ++u) {
+                double row = 0.0;
+                for (int w = 0; w < 3; ++w) row += p.g[b * 3 + w] * src(u, w);
+                acc += p.g[a * 3 + u] * row;
+            }
+            v = (float)acc;
+        } else {
+            double acc = 0.0;
+            for (int j = 0; j < 5; ++j) acc += p.g[t * 5 + j] * (p.kh == 1 ? src(0, j) : src(j, 0));
+            v = (float)acc;
+        }
+    }
+    p.wp[i] = v;
+}
+
+extern "C" int raft_pack_train_conv_f32(const float *kernel, const float *bias, int kh, int kw, int cin, int cout, int dgrad,
+                                        int mode, const double *g, int gt, int kpad, int npad, float *wp, float *bias_out,
+                                        void *stream) {
+    RAFT_REQUIRE_PTR(kernel);
+    RAFT_REQUIRE_PTR(wp);
+    RAFT_REQUIRE_PTR(bias_out);
+    RAFT_REQUIRE(kh > 0 && kw > 0 && cin > 0 && cout > 0 && kpad > 0 && npad > 0, RAFT_E_SHAPE);
+    RAFT_REQUIRE(kpad % 4 == 0 && kpad >= (dgrad ? cout : cin) && npad >= (dgrad ? cin : cout), RAFT_E_SHAPE);
+    RAFT_REQUIRE(mode == 0 || (mode == 1 && kh == 3 && kw == 3) || (mode == 2 && ((kh == 1 && kw == 5) || (kh == 5 && kw == 1)) && gt > 0 && gt <= 8),
+                 RAFT_E_UNSUPPORTED);
+    RAFT_REQUIRE(!dgrad || (kh % 2 == 1 && kw % 2 == 1), RAFT_E_UNSUPPORTED);
+    PackTrainArgs a = {};
+    a.kernel = kernel; a.bias = bias; a.wp = wp; a.bias_out = bias_out;
+    a.kh = kh; a.kw = kw; a.cin = cin; a.cout = cout; a.dgrad = dgrad; a.mode = mode; a.gt = gt; a.kpad = kpad; a.npad = npad;
+    if (mode != 0) {
+        RAFT_REQUIRE_PTR(g);
+        const int ng = mode == 1 ? 12 : gt * 5;
+        for (int i = 0; i < ng; ++i) a.g[i] = g[i];
+    }
+    const int taps = mode == 0 ? kh * kw : (mode == 1 ? 16 : gt);
+    const int64_t total = (int64_t)taps * kpad * npad;
+    RAFT_REQUIRE(total / 256 < 0x7fffffff, RAFT_E_UNSUPPORTED);
+    pack_train_kernel<<<raft_ceil_div(total > npad ? total : npad, 256), 256, 0, (hipStream_t)stream>>>(a);
+    return raft_launch_status();
+}

@@ -9,6 +9,8 @@ concatenates here; every multiply-add is a HIP kernel.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 
 import numpy as np
@@ -105,6 +107,39 @@ def _pack_conv_any(kernel, bias, sources):
     if bias is not None:
         b[:cout] = _dev_param(bias)
     return wp, b, npad
+
+
+_G_CTYPES = {}
+
+
+def _pack_train_device(kernel, bias, wino, dgrad, cpad):
+    """``_pack_conv_any([_wino_transform_any]([_dgrad_kernel_any](kernel)), bias, [(K, cpad)])`` for a DEVICE kernel in ONE launch
+    (``raft_pack_train_conv_f32``): the master weights change every step, and the tensor-op version of this chain was ~10 small
+    kernels per layer and use.  ``wino``: None / '2d' / '1d' (F(4, 5)); returns (wp, bias, npad) like the chain it replaces."""
+    import ctypes as C
+    kh, kw, cin, cout = kernel.shape
+    k_ch, n_ch = (cout, cin) if dgrad else (cin, cout)
+    if cpad < k_ch or cpad % 4:
+        raise ValueError(f'padded source width {cpad} does not hold {k_ch} channels')
+    npad = packing.round_up(n_ch, 64)
+    mode = {None: 0, '2d': 1, '1d': 2}[wino]
+    taps = kh * kw if mode == 0 else (16 if mode == 1 else 8)
+    gkey = {1: '_WINO_G', 2: '_WINO1D4_G'}.get(mode)
+    if gkey is not None and gkey not in _G_CTYPES:
+        g = np.ascontiguousarray(getattr(packing, gkey), dtype=np.float64).ravel()
+        _G_CTYPES[gkey] = (C.c_double * g.size)(*g)
+    kernel = kernel.contiguous()
+    wp = torch.empty((taps, cpad // 4, npad, 4), device=kernel.device, dtype=torch.float32)
+    b = torch.empty((npad,), device=kernel.device, dtype=torch.float32)
+    bias_t = None if (bias is None or dgrad) else _dev_param(bias).contiguous()
+    check(_dev.lib().raft_pack_train_conv_f32(_dev.ptr(kernel), _dev.ptr(bias_t) if bias_t is not None else None, kh, kw, cin, cout,
+                                              1 if dgrad else 0, mode, _G_CTYPES.get(gkey), 8 if mode == 2 else 0, cpad, npad,
+                                              _dev.ptr(wp), _dev.ptr(b), _dev.stream_ptr()), 'pack_train_conv')
+    return wp, b, npad
+
+
+# RAFT_TRAIN_PACK=torch restores the tensor-op packing chain (tests compare the two)
+FUSED_TRAIN_PACK = os.environ.get('RAFT_TRAIN_PACK', 'hip') != 'torch'
 
 
 # The training forward and the input gradients run the 3x3 / 1x5 / 5x1 layers on the Winograd kernels of the inference path
@@ -300,6 +335,8 @@ def conv2d_backward(x, kernel, dy, y=None, defer=None):
     wino = _wino_kind(kh, kw)
 
     def make_d():
+        if FUSED_TRAIN_PACK and _is_t(kernel):
+            return _pack_train_device(kernel, None, wino, True, cpad)
         kd = _dgrad_kernel_any(kernel)
         return _pack_conv_any(_wino_transform_any(kd) if wino else kd, None, [(cout, cpad)])
     wp_d, b_d, npad = _cached(kernel, 'dgrad' + (wino or ''), make_d)
@@ -325,7 +362,10 @@ def _conv_fwd(x, kernel, bias, act=0, scale=1.0):
     B, H, W, c = x.shape
     cpad = packing.round_up(cin, 32)
     wino = _wino_kind(kh, kw)
-    make = lambda: _pack_conv_any(_wino_transform_any(kernel) if wino else kernel, bias, [(cin, cpad)])
+    def make():
+        if FUSED_TRAIN_PACK and _is_t(kernel) and (bias is None or _is_t(bias)):
+            return _pack_train_device(kernel, bias, wino, False, cpad)
+        return _pack_conv_any(_wino_transform_any(kernel) if wino else kernel, bias, [(cin, cpad)])
     wp_d, b_d, npad = _cached(kernel, 'fwd' + (wino or ''), make, also=bias) if isinstance(bias, (np.ndarray, torch.Tensor)) else make()
     xp = x
     if cpad != c:
