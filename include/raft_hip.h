@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_VERSION 218          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
+#define RAFT_HIP_VERSION 219          /* 0.2.0: ABI stamp, checked by the Python binding -- bump on ANY struct / signature change */
 #define RAFT_MAX_LEVELS 4
 
 enum {
@@ -85,6 +85,13 @@ const char *raft_error_string(int rc);
  * NULL = back to the load-time (environment) state.  RAFT_E_UNSUPPORTED for an unknown name.  Thread-safe; takes effect
  * for launches enqueued after the call. */
 int raft_set_option(const char *name, const char *value);
+/* Launch-shape hint of the CALLING THREAD (thread-local, not process-global): its subsequent launches share the device with
+ * n - 1 other independent launch sequences of about the same size -- the lanes of tf_raft_amd/model.py's pipelined forward,
+ * several recurrent loops in flight on streams of their own.  The launchers' "does this grid fill the chip?" rules (Winograd
+ * variant per layer, K-split / channel width of a workgroup, fused mask head) then count a grid n times, i.e. choose the
+ * shapes of an n-times larger batch: less CU-time per launch instead of less latency.  Every shape computes the same function
+ * within the per-kernel tolerances (as with the switches above).  n <= 1 restores the default.  Returns the previous value. */
+int raft_set_thread_concurrency(int n);
 /* Current value as text into buf ("" while unset). */
 int raft_get_option(const char *name, char *buf, size_t len);
 
@@ -331,6 +338,10 @@ int raft_loop_ctx_destroy(raft_loop_ctx *ctx);
  * convex upsample) run on the caller-owned side streams aux0 / aux1 next to the main chain on `stream`,
  * ordered by events; everything is joined back into `stream` before the call returns (it still only
  * enqueues).  Results are identical to raft_iterate_basic_f32.
+ * aux0 == aux1 == stream selects the SINGLE-STREAM schedule (the launches of raft_iterate_basic_f32, no events) for
+ * this and the two entry points below: what a caller that keeps several loops in flight on streams of their own
+ * (tf_raft_amd/model.py, lanes of the pipelined forward) runs on each.  Any other coincidence of the three streams is
+ * RAFT_E_UNSUPPORTED.
  * With RAFT_LOOP_GRAPH on (off by default) the first call with a given set of arguments (pointers, sizes,
  * streams) captures these launches into a hipGraph kept in `ctx`; later calls with the same arguments replay it with ONE
  * hipGraphLaunch on `stream` -- the reference's canonical (1,448,512,3) call is bound by the host's ~350 launches + ~100

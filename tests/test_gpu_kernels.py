@@ -287,7 +287,8 @@ def test_corr_lookup_ondemand_matches_oracle(rng, shape, C, sigma):
             assert np.all(got[..., :(2 * radius + 1) ** 2] == 0.0)       # level 0 on the integer grid: identically 0
 
 
-@pytest.mark.parametrize('shape', [(2, 7, 9), (1, 6, 8), (3, 2, 1)])   # odd width: the last pixel pair is half empty
+@pytest.mark.parametrize('shape', [(2, 7, 9), (1, 6, 8), (3, 2, 1),   # odd width: the last pixel pair is half empty
+                                   (1, 56, 64), (1, 128, 128), (2, 46, 62)])   # BASELINE's 448x512 / 1024x1024 maps, the training crop
 def test_upsample_convex_matches_oracle(rng, shape):
     from oracle.model import upsample_flow
     from tf_raft_amd import RAFT
@@ -781,3 +782,81 @@ def test_update_block_rejects_wrong_shapes(rng):
         blk([net, inp, corr[..., :100], flow])
     with pytest.raises(ValueError):
         BasicUpdateBlock(filters=64)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_c_abi_from_two_host_threads(rng):
+    """the C ABI is re-entrant and thread-safe -- calls only enqueue on the stream they are given and the
+    library keeps no per-call state.  Two host threads (ctypes drops the GIL inside a call), each on a stream of its own with
+    buffers of its own, run volume build -> pyramid lookup -> fused lookup + convc1 -> convex upsampling and a whole RAFT forward
+    concurrently, 12 rounds each; one of the threads launches under a thread-local shape hint (raft_set_thread_concurrency),
+    which must not leak into the other.  Every result must equal, bit for bit, what the same thread's work returns when it runs
+    alone.  (The host side of the ABI -- argument validation, the option table -- runs under ASan / TSan in
+    tests/test_abi_sanitizers.py.)"""
+    import threading
+    import tf_raft_amd
+    from tf_raft_amd import _dev, _ffi, packing
+    from tf_raft_amd import weights as wm
+    from tf_raft_amd._ffi import check
+    from tf_raft_amd.layers.corr import CorrBlock
+    lib = _dev.lib()
+    B, h, w = 2, 24, 32
+    wts = wm.init_weights('raft', seed=5, perturb=True)
+
+    def make_work(seed, hint):
+        r = np.random.default_rng(seed)
+        f1 = _dev.to_device(r.normal(size=(B, h, w, 256)).astype(np.float32))
+        f2 = _dev.to_device(r.normal(size=(B, h, w, 256)).astype(np.float32))
+        ys, xs = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing='ij')
+        coords = _dev.to_device((np.stack([xs, ys], -1)[None].repeat(B, 0) + r.normal(scale=3.0, size=(B, h, w, 2))).astype(np.float32))
+        flow = _dev.to_device(r.normal(scale=4.0, size=(B, h, w, 2)).astype(np.float32))
+        mask = _dev.to_device(r.normal(size=(B, h, w, 576)).astype(np.float32))
+        kc1 = (r.normal(size=(1, 1, 324, 256)) * 0.05).astype(np.float32)
+        wp, bias, npad = packing.pack_convc1_fused(kc1, r.normal(size=256).astype(np.float32))
+        wp_d, bias_d = _dev.to_device(wp), _dev.to_device(bias)
+        img1 = _dev.to_device(r.uniform(0, 255, size=(1, 128, 160, 3)).astype(np.float32))
+        img2 = _dev.to_device(r.uniform(0, 255, size=(1, 128, 160, 3)).astype(np.float32))
+        model = tf_raft_amd.RAFT(weights=wts, iters_pred=4, pipeline=False, overlap=False, loop_concurrency=hint)
+        stream = torch.cuda.Stream()
+
+        def once():
+            with torch.cuda.stream(stream), _ffi.thread_concurrency(hint):
+                corr = CorrBlock(f1, f2, 4, 4)
+                look = torch.empty((B, h, w, 352), device='cuda')
+                corr.retrieve(coords, out=look, ld_out=352)
+                cor1 = torch.empty((B, h, w, 256), device='cuda')
+                check(lib.raft_lookup_convc1_f32(_dev.ptr(corr._pyr), corr._off, _dev.ptr(coords), B, h, w, _dev.ptr(wp_d), _dev.ptr(bias_d),
+                                                 npad, 256, _dev.ptr(cor1), 256, _dev.stream_ptr()), 'lookup_convc1')
+                up = torch.empty((B, 8 * h, 8 * w, 2), device='cuda')
+                check(lib.raft_upsample_convex_f32(_dev.ptr(flow), _dev.ptr(mask), B, h, w, _dev.ptr(up), _dev.stream_ptr()), 'upsample')
+                pred = model([img1, img2])[-1].as_subclass(torch.Tensor)
+                outs = [look[..., :324].clone(), cor1, up, pred.clone()]
+            stream.synchronize()
+            return [o.cpu().numpy() for o in outs]
+        return once
+
+    works = [make_work(11, 1), make_work(12, 3)]
+    alone = [wk() for wk in works]                       # each thread's work run alone (and once more: deterministic)
+    for wk, ref in zip(works, alone):
+        for a, b in zip(wk(), ref):
+            np.testing.assert_array_equal(a, b)
+    errors, rounds = [], 12
+    barrier = threading.Barrier(2)
+
+    def run(k):
+        try:
+            barrier.wait()
+            for _ in range(rounds):
+                for a, b in zip(works[k](), alone[k]):
+                    np.testing.assert_array_equal(a, b)
+            assert lib.raft_set_thread_concurrency(1) == 1          # the other thread's hint never became this thread's
+        except BaseException as e:  # noqa: BLE001
+            errors.append((k, repr(e)[:500]))
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    report('C ABI from two host threads', rounds_per_thread=rounds, results_compared_bitwise=2 * rounds * 4)

@@ -379,18 +379,23 @@ def test_north_star_benchmarked_batches():
         _assert_oracle_is_well_conditioned(f'raft_448x512_seed3_it24_conditioned_batch8_element{b}')
     i1, i2, wts = _conditioned_case('raft', 448, 512, 3, B=8)
     want = [oracle.RAFT(wts, iters_pred=24)([i1[b:b + 1], i2[b:b + 1]]) for b in range(8)]
-    for B in (2, 3, 4, 6, 8):
-        model = tf_raft_amd.RAFT(weights=wts, iters_pred=24)
+    # round 6: each batch also through the multi-lane pipelined forward (what bench.py times): three calls in flight, every
+    # loop launched with the kernel shapes of a lanes-times larger batch (raft_set_thread_concurrency); the LAST call is checked
+    for B, lanes in [(b, l) for b in (2, 3, 4, 6, 8) for l in (0, 3)] + [(1, 3)]:
+        model = tf_raft_amd.RAFT(weights=wts, iters_pred=24, pipeline=bool(lanes), lanes=max(lanes, 1))
+        if lanes:
+            model([i1[:B], i2[:B]])
+            model([np.asarray(i1[:B])[::-1].copy(), i2[:B]])
         got = model([i1[:B], i2[:B]])
         worst = 0.0
         for b in range(B):
             errs = [_max_epe(_np(g)[b:b + 1], w) for g, w in zip(got, want[b])]
             worst = max(worst, max(errs))
-            assert errs[-1] <= TOL, (B, b, errs[-1])
-            assert max(errs) <= TOL, (B, b, errs)
+            assert errs[-1] <= TOL, (B, lanes, b, errs[-1])
+            assert max(errs) <= TOL, (B, lanes, b, errs)
         last = model.predict_step((i1[:B], i2[:B]))
         np.testing.assert_array_equal(last.numpy(), got[-1].numpy())
-        report(f'north-star raft 448x512 B={B}', worst_epe_any_iteration_any_element=worst)
+        report(f'north-star raft 448x512 B={B} {"lanes=%d" % lanes if lanes else "serial"}', worst_epe_any_iteration_any_element=worst)
 
 
 def _first_above(errs, tol):
@@ -501,14 +506,17 @@ def test_jump_regime_benchmarked_batches():
         _assert_jump_fixture(f'raft_448x512_seed5_it24_jump5_batch8_element{b}', 2e-4)
     i1, i2, wts = _jump_case('raft', 448, 512, 5, B=8)
     want = [oracle.RAFT(wts, iters_pred=24)([i1[b:b + 1], i2[b:b + 1]]) for b in range(8)]
-    for B in (2, 4, 8):
-        got = tf_raft_amd.RAFT(weights=wts, iters_pred=24)([i1[:B], i2[:B]])
+    for B, lanes in [(2, 0), (4, 0), (8, 0), (1, 3), (4, 3), (8, 3)]:   # lanes: the multi-lane pipelined forward (round 6), last of three calls in flight
+        model = tf_raft_amd.RAFT(weights=wts, iters_pred=24, pipeline=bool(lanes), lanes=max(lanes, 1))
+        for _ in range(2 if lanes else 0):
+            model([i1[:B], i2[:B]])
+        got = model([i1[:B], i2[:B]])
         worst = 0.0
         for b in range(B):
             errs = [_max_epe(_np(g)[b:b + 1], w) for g, w in zip(got, want[b])]
             worst = max(worst, max(errs))
-            assert max(errs) <= TOL, (B, b, errs)
-        report(f'jump regime raft 448x512 B={B}', worst_epe_any_iteration_any_element=worst)
+            assert max(errs) <= TOL, (B, lanes, b, errs)
+        report(f'jump regime raft 448x512 B={B} {"lanes=%d" % lanes if lanes else "serial"}', worst_epe_any_iteration_any_element=worst)
 
 
 def test_jump_regime_alternate_corr_1024_all_24_iterations():
@@ -697,7 +705,13 @@ def test_alternate_corr_model_matches_volume_model():
 
 
 @pytest.mark.parametrize('variant,kw,shape,iters', [('raft', {}, (2, 128, 192), 6), ('raft', {}, (4, 448, 512), 5), ('small', {}, (2, 128, 192), 6),
-                                                     ('raft', {'alternate_corr': True}, (1, 256, 320), 4)])
+                                                     ('raft', {'alternate_corr': True}, (1, 256, 320), 4),
+                                                     # round 6: several loops in flight, each on streams of its own
+                                                     ('raft', {'lanes': 2}, (4, 448, 512), 5), ('raft', {'lanes': 3}, (2, 128, 192), 6),
+                                                     ('raft', {'lanes': 2, 'overlap': False}, (2, 128, 192), 6),
+                                                     ('raft', {'lanes': 4, 'overlap': False}, (4, 448, 512), 4),
+                                                     ('small', {'lanes': 2}, (2, 128, 192), 6),
+                                                     ('raft', {'lanes': 2, 'alternate_corr': True}, (1, 256, 320), 4)])
 def test_pipelined_calls_are_bitwise_the_serial_calls(variant, kw, shape, iters):
     """Round 5: consecutive inference calls overlap -- the loop of call n runs on the 'loop' stream while the caller's stream
     already runs the encoders and the volume build of call n + 1 (tf_raft_amd/model.py, "pipelined forward").  Every call's
@@ -710,7 +724,10 @@ def test_pipelined_calls_are_bitwise_the_serial_calls(variant, kw, shape, iters)
     wts = wm.init_weights(variant, seed=3, perturb=True)
     B, H, W = shape
     pipe = cls(weights=wts, iters_pred=iters, pipeline=True, **kw)
-    serial = cls(weights=wts, iters_pred=iters, pipeline=False, **kw)
+    # several lanes launch their loops with the kernel shapes of a lanes-times larger batch (raft_set_thread_concurrency): the
+    # serial reference is given the same hint, so that only the SCHEDULE differs
+    serial = cls(weights=wts, iters_pred=iters, pipeline=False, loop_concurrency=kw.get('lanes', 1),
+                 **{k: v for k, v in kw.items() if k != 'lanes'})
     assert pipe.pipeline and not serial.pipeline
     inputs = [tuple(torch.as_tensor(a).cuda() for a in _images(40 + k, B, H, W)) for k in range(5)]
     torch.cuda.synchronize()
@@ -734,7 +751,7 @@ def test_pipelined_calls_are_bitwise_the_serial_calls(variant, kw, shape, iters)
             del last
             torch.empty((iters, B, H, W, 2), device='cuda').fill_(float('nan'))
     np.testing.assert_array_equal(last[-1].cpu().numpy(), got[4][-1])
-    if variant == 'raft' and not kw:
+    if variant == 'raft' and not (set(kw) - {'lanes'}):
         # predict_step (final-only loop) through the same pipeline, shape change in between (ring re-allocation)
         ps = [pipe.predict_step((a, b)) for a, b in inputs[:3]]
         small_in = tuple(torch.as_tensor(x).cuda() for x in _images(77, 1, 64, 96))
@@ -751,7 +768,8 @@ def test_weights_replaced_while_a_pipelined_call_is_in_flight():
     from tf_raft_amd import weights as wm
     w_a, w_b = wm.init_weights('raft', seed=11, perturb=True), wm.init_weights('raft', seed=12, perturb=True)
     a, b = (torch.as_tensor(x).cuda() for x in _images(8, 2, 128, 192))
-    serial = tf_raft_amd.RAFT(weights=w_a, iters_pred=8, pipeline=False)
+    from tf_raft_amd.model import DEFAULT_LANES
+    serial = tf_raft_amd.RAFT(weights=w_a, iters_pred=8, pipeline=False, loop_concurrency=DEFAULT_LANES)   # the pipelined model's kernel shapes
     want_a = serial([a, b])[-1].cpu().numpy()
     serial.set_weights(w_b)
     want_b = serial([a, b])[-1].cpu().numpy()
@@ -772,8 +790,9 @@ def test_pending_results_join_whichever_stream_touches_them_first():
     reads do not wait."""
     import tf_raft_amd
     from tf_raft_amd import _dev
+    from tf_raft_amd.model import DEFAULT_LANES
     model = tf_raft_amd.RAFT(iters_pred=8, pipeline=True)
-    serial = tf_raft_amd.RAFT(iters_pred=8, pipeline=False)
+    serial = tf_raft_amd.RAFT(iters_pred=8, pipeline=False, loop_concurrency=DEFAULT_LANES)
     a, b = (torch.as_tensor(x).cuda() for x in _images(5, 2, 128, 192))
     want = serial([a, b])[-1].cpu().numpy()
     out = model([a, b])

@@ -647,3 +647,35 @@ def test_pending_results_join_on_every_route_to_their_bytes():
     plain = _dev.wrap(torch.zeros(2))                          # results of the serial path carry no Pending
     assert plain.__dict__.get('_pending') is None and float((plain + 1).sum()) == 2.0
     assert _dev.join([plain, torch.zeros(1), None]) is not None
+    # tensors inside keyword containers at any depth, the dlpack protocol (pickling / deepcopy: next test)
+    for touch in (lambda x: torch.cat(tensors=[x, x]), lambda x: torch.stack(tensors=(x, x)), lambda x: torch.from_dlpack(x),
+                  lambda x: x.__dlpack__()):
+        t, p = fresh()
+        touch(t)
+        assert p.n >= 1, touch
+
+
+def test_a_real_pending_pickles_as_none_after_joining():
+    """``Pending`` holds a HIP event; a pickled / deep-copied result tensor is read behind a join and carries no Pending."""
+    import copy
+    import pickle
+    from tf_raft_amd import _dev
+
+    class Ev:
+        waited = 0
+
+    class P(_dev.Pending):
+        def join(self):
+            Ev.waited += 1
+
+    t = _dev.wrap(torch.ones(3), P(object(), torch.device('cpu')))
+    u = pickle.loads(pickle.dumps(t))
+    assert Ev.waited >= 1 and u.__dict__.get('_pending') is None and float(u.sum()) == 3.0
+    v = copy.deepcopy(t)
+    assert v.__dict__.get('_pending') is None and float(v.sum()) == 3.0
+    import io
+    buf = io.BytesIO()
+    torch.save(t, buf)
+    buf.seek(0)
+    w = torch.load(buf, weights_only=False)
+    assert w.__dict__.get('_pending') is None and float(w.sum()) == 3.0

@@ -42,10 +42,35 @@ class Pending:
             torch.cuda.current_stream(self.device).wait_event(self.event)
             self._joined.add(sid)
 
+    def __reduce__(self):
+        # pickling / deepcopy of a result tensor copies its __dict__: the copy's bytes are read on the current stream (ordered
+        # behind the loop here), and an event cannot travel -- the copy carries no Pending
+        self.join()
+        return (_no_pending, ())
+
+
+def _no_pending():
+    return None
+
 
 # attribute reads that say nothing about the tensor's bytes: no ordering needed
 _METADATA = frozenset(('shape', 'dtype', 'device', 'is_cuda', 'ndim', 'layout', 'requires_grad', 'grad', 'grad_fn', 'is_leaf',
                        'names', 'is_sparse', 'is_quantized', 'is_meta', 'output_nr', '_version', 'is_cpu', 'itemsize', 'nbytes'))
+
+
+def _join_nested(items):
+    """Join every pending DeviceTensor among ``items``, looking into lists / tuples / dicts at any depth (``torch.cat(tensors=[..])``,
+    ``torch.stack(tensors=(..))``, nested containers)."""
+    for a in items:
+        t = type(a)
+        if t is DeviceTensor:
+            p = a.__dict__.get('_pending')
+            if p is not None:
+                p.join()
+        elif t in (list, tuple):
+            _join_nested(a)
+        elif t is dict:
+            _join_nested(a.values())
 
 
 class DeviceTensor(torch.Tensor):
@@ -59,19 +84,9 @@ class DeviceTensor(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         if not (getattr(func, '__name__', '') == '__get__' and getattr(getattr(func, '__self__', None), '__name__', '') in _METADATA):
-            for a in args:
-                if type(a) is DeviceTensor:
-                    p = a.__dict__.get('_pending')
-                    if p is not None:
-                        p.join()
-                elif type(a) in (list, tuple):
-                    for b in a:
-                        if type(b) is DeviceTensor and b.__dict__.get('_pending') is not None:
-                            b.__dict__['_pending'].join()
+            _join_nested(args)
             if kwargs:
-                for a in kwargs.values():
-                    if type(a) is DeviceTensor and a.__dict__.get('_pending') is not None:
-                        a.__dict__['_pending'].join()
+                _join_nested(kwargs.values())
         return super().__torch_function__(func, types, args, kwargs or {})
 
     def join(self):
@@ -84,6 +99,16 @@ class DeviceTensor(torch.Tensor):
     def as_subclass(self, cls):   # type: ignore[override]   (not routed through __torch_function__)
         self.join()
         return super().as_subclass(cls)
+
+    def __deepcopy__(self, memo):
+        self.join()
+        c = wrap(torch.Tensor.as_subclass(self, torch.Tensor).detach().clone())     # a copy is complete: no Pending
+        memo[id(self)] = c
+        return c
+
+    def __dlpack__(self, *args, **kwargs):   # type: ignore[override]   (torch.from_dlpack / np.from_dlpack / other frameworks)
+        self.join()
+        return super().__dlpack__(*args, **kwargs)
 
     def numpy(self):   # type: ignore[override]
         return self.detach().as_subclass(torch.Tensor).cpu().numpy()
@@ -145,10 +170,11 @@ _SIDE_STREAMS = {}
 
 
 def side_stream(device, role: str, priority: int = 0) -> 'torch.cuda.Stream':
-    """The process-wide side stream of ``role`` ('flow', 'mask', 'encoder', 'loop') on ``device`` (``priority`` applies when
-    the stream is first created)."""
+    """The process-wide side stream of ``role`` ('flow', 'mask', 'encoder', 'loop'; lane k > 0 of the pipelined forward:
+    'loop1', 'flow1', ...) and ``priority`` on ``device``.  Streams of different priorities are different streams (a
+    stream's priority is fixed when it is created)."""
     device = torch.device(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role, int(priority))
     s = _SIDE_STREAMS.get(key)
     if s is None:
         s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)

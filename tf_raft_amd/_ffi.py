@@ -11,7 +11,7 @@ import threading
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 218     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
+ABI_VERSION = 219     # include/raft_hip.h RAFT_HIP_VERSION: the ctypes mirrors below describe THIS revision of the structs
 
 c_float_p = C.c_void_p      # raw device pointers travel as void*
 c_i64_p = C.POINTER(C.c_int64)
@@ -60,6 +60,7 @@ _SIGNATURES = {
     'raft_error_string': (C.c_char_p, [_I]),
     'raft_set_option': (_I, [C.c_char_p, C.c_char_p]),
     'raft_get_option': (_I, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    'raft_set_thread_concurrency': (_I, [_I]),
     'raft_loop_ctx_create': (_I, [C.POINTER(C.c_void_p)]),
     'raft_loop_ctx_destroy': (_I, [C.c_void_p]),
     'raft_crc32c': (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
@@ -211,6 +212,22 @@ def set_option(name: str, value) -> None:
     """``raft_set_option``: ``value`` None = load-time (environment) state, '' = built-in default."""
     v = None if value is None else str(value).encode()
     check(load_library().raft_set_option(name.encode(), v), f'set_option {name}')
+
+
+class thread_concurrency:
+    """``with thread_concurrency(n):`` -- ``raft_set_thread_concurrency`` for the enclosed launches of the calling thread (n
+    independent launch sequences share the device: shapes for CU-time instead of latency), restored on exit."""
+
+    def __init__(self, n: int):
+        self.n, self.prev = int(n), 1
+
+    def __enter__(self):
+        self.prev = load_library().raft_set_thread_concurrency(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        load_library().raft_set_thread_concurrency(self.prev)
+        return False
 
 
 def get_option(name: str) -> str:

@@ -117,6 +117,79 @@ def _build_locked(force: bool, verbose: bool) -> str:
     return LIBPATH
 
 
+def build_sanitizer_library(kind: str = 'address', verbose: bool = False) -> str:
+    """HOST-ONLY build of the library under a sanitizer (``kind`` = 'address' or 'thread'):
+    ``hipcc --offload-host-only -fsanitize=<kind>`` of the same sources -> ``lib/libraft_hip_host_<kind>.so``.  It holds no
+    device code (GPU AddressSanitizer needs xnack+ code objects, which this pool refuses) and is never loaded by the product:
+    tests/test_abi_sanitizers.py links ``tests/native/abi_host_check.cpp`` against it to run everything an entry point does
+    before it launches -- argument validation, geometry arithmetic, the option table -- from several host threads."""
+    if kind not in ('address', 'thread'):
+        raise ValueError(f"kind must be 'address' or 'thread', got {kind!r}")
+    srcs, hdrs = _inputs()
+    out = os.path.join(LIBDIR, f'libraft_hip_host_{kind}.so')
+    stamp = out + '.sha256'
+    digest = _digest(srcs + hdrs) + ':' + kind
+    if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        return out
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    flags = ['--offload-host-only', f'-fsanitize={kind}', '-O1', '-g', '-fno-omit-frame-pointer', '-std=c++17', '-fPIC',
+             '-ffp-contract=on', '-Wno-unused-function', '-Wno-unused-value']
+
+    def compile_one(src):
+        obj = os.path.join(LIBDIR, os.path.basename(src) + f'.host_{kind}.o')
+        cmd = [hipcc, *flags, '-x', 'hip', '-c', src, '-o', obj]
+        if verbose:
+            print('[build]', ' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    # a host-only object still refers to the device image its kernels would live in (__hip_fatbin_<hash>): give every such
+    # symbol an empty definition -- nothing here ever launches
+    syms = set()
+    for o in objs:
+        for line in subprocess.run(['nm', '-u', o], check=True, capture_output=True, text=True).stdout.splitlines():
+            name = line.split()[-1] if line.split() else ''
+            if name.startswith('__hip_fatbin_'):
+                syms.add(name)
+    stub_c = os.path.join(LIBDIR, f'fatbin_stubs_{kind}.c')
+    with open(stub_c, 'w') as f:
+        f.write('/* generated by tf_raft_amd/build.py build_sanitizer_library */\n')
+        for name in sorted(syms):
+            f.write(f'const char {name}[64] __attribute__((aligned(4096))) = {{0}};\n')
+    stub_o = stub_c[:-2] + '.o'
+    subprocess.run(['gcc', '-fPIC', '-c', stub_c, '-o', stub_o], check=True)
+    subprocess.run([hipcc, '--offload-host-only', f'-fsanitize={kind}', '-shared-libsan', '-shared', '-fPIC', *objs, stub_o, '-o', out], check=True)
+    for o in objs + [stub_c, stub_o]:
+        os.remove(o)
+    with open(stamp, 'w') as f:
+        f.write(digest)
+    return out
+
+
+def build_abi_host_check(kind: str = 'address', verbose: bool = False) -> str:
+    """``tests/native/abi_host_check.cpp`` linked against the host-only sanitizer build; returns the executable."""
+    lib = build_sanitizer_library(kind, verbose)
+    root = os.path.normpath(os.path.join(HERE, '..'))
+    src = os.path.join(root, 'tests', 'native', 'abi_host_check.cpp')
+    exe = os.path.join(LIBDIR, f'abi_host_check_{kind}')
+    clang = os.path.join(os.path.dirname(os.path.realpath(_hipcc())), '..', 'lib', 'llvm', 'bin', 'clang++')
+    if not os.path.exists(clang):
+        clang = '/opt/rocm/lib/llvm/bin/clang++'
+    cmd = [clang, f'-fsanitize={kind}', '-shared-libsan', '-O1', '-g', '-std=c++17', '-pthread', '-I', os.path.join(root, 'include'), src,
+           lib, f'-Wl,-rpath,{LIBDIR}', '-o', exe]
+    if verbose:
+        print('[build]', ' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return exe
+
+
 if __name__ == '__main__':
+    if '--sanitize' in sys.argv:
+        for k in ('address', 'thread'):
+            print(build_abi_host_check(k, verbose=True))
+        sys.exit(0)
     build_library(force='--force' in sys.argv)
     print(LIBPATH)

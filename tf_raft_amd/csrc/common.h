@@ -73,6 +73,9 @@ enum RaftOptionId {
     RAFT_OPT_COUNT
 };
 int raft_opt(int id, int dflt);
+// raft_set_thread_concurrency (include/raft_hip.h): how many independent launch sequences of about this size share the device
+// with the calling thread's launches (>= 1).  The launchers' "does this grid fill the chip?" rules count a grid n times.
+int raft_concurrency();
 bool raft_opt_is_set(int id);
 int raft_opt_generation();   // bumped by every raft_set_option call
 // RAFT_CONV_TILE ("<code>" or "<npad>:<taps>:<code>,..."): the tile code forced for a convolution, or -1

@@ -19,7 +19,7 @@ int raft_launch_mask_upsample(const float *a, int lda, const float *wp, const fl
 // 246.3 -> 256.3 at three (profiles/r09e_small_batch_mask.txt); a single pair stays on the two-kernel path (152 - 153 against
 // 148 - 155).
 static bool mask_is_fused(const raft_basic_update_weights *wts, int64_t pixels) {
-    return raft_opt(RAFT_OPT_MASK_FUSED, pixels >= 2 * 3584 ? 1 : 0) != 0 && wts->mask2.wp != nullptr && wts->mask2.npad == 576;
+    return raft_opt(RAFT_OPT_MASK_FUSED, pixels * raft_concurrency() >= 2 * 3584 ? 1 : 0) != 0 && wts->mask2.wp != nullptr && wts->mask2.npad == 576;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -51,7 +51,7 @@ static int pick_code(const ConvArgs &a, int kh, int kw) {
         for (int tn = 1; tn <= 2; ++tn) {
             const int th = ths[ti];
             if (a.npad % (64 * tn)) continue;
-            const int64_t blocks = (int64_t)a.B * ((a.H + th - 1) / th) * ((a.W + 15) / 16) * (a.npad / (64 * tn));
+            const int64_t blocks = (int64_t)a.B * ((a.H + th - 1) / th) * ((a.W + 15) / 16) * (a.npad / (64 * tn)) * raft_concurrency();
             const int64_t per_cu = (blocks + 255) / 256;
             const int lds = 2 * ((th + kh - 1) * (16 + kw - 1) * 40 + 8) * 4;
             int resident = 160 * 1024 / lds;
@@ -207,7 +207,7 @@ static int launch_gru_conv(const raft_conv_weights &direct, const raft_conv_weig
     // F(4, 5) wins where the launch fills the chip; below ~2 x 3584 pixels (the reference's single 448 x 512 pair) every
     // kernel is one under-filled round of workgroups and the F(2, 5) kernel's smaller workgroups finish sooner
     // (B = 1: 8.69 -> 8.40 ms per forward, profiles/r05d_b1_probe.txt)
-    const int mask4 = raft_opt(RAFT_OPT_GRU_WINO4, (int64_t)a.B * a.H * a.W < 2 * 3584 ? 0 : RAFT_GRU_WINO4_DEFAULT);
+    const int mask4 = raft_opt(RAFT_OPT_GRU_WINO4, (int64_t)a.B * a.H * a.W * raft_concurrency() < 2 * 3584 ? 0 : RAFT_GRU_WINO4_DEFAULT);
     if ((mask4 & bit) && wino4.wp != nullptr && a.c0 % 32 == 0 && a.c1 % 32 == 0) {
         a.wp = wino4.wp;
         a.bias = wino4.bias;
@@ -246,7 +246,7 @@ constexpr int RAFT_SMALL_WINO_DEFAULT = 15;   // SmallRAFT: {1: conv, 2: gru_zr,
 // branch no longer competes with convc2, which can have its faster shape back (one process, profiles/r09i_b4_options3.txt:
 // 303.1 pairs/s -> 325.9 at 4 pairs; with convc2 on 8-row workgroups 303.3; 8 pairs 345.0 -> 353.3).
 static int wino4_default_mask(const ConvArgs &a) {
-    const int64_t m = (int64_t)a.B * a.H * a.W;
+    const int64_t m = (int64_t)a.B * a.H * a.W * raft_concurrency();   // loops sharing the chip fill it like one loop of n times the batch
     return m < 2 * 3584 ? 0 : (8 | (m >= 3 * 3584 ? 1 | 2 : 0) | (m >= 8 * 3584 ? 4 : 0));   // three pairs: 250 -> 262 pairs/s with 11, two: 237 -> 231
 }
 static int launch_conv3x3(const raft_conv_weights &direct, const raft_conv_weights &wino, int bit, ConvArgs a, int epi,
@@ -711,7 +711,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         // 56 of them beside convc2's 168 and the mask branch's 32: 353.4 -> 356.1 pairs/s, profiles/r09k_b8_options.txt)
         const int f2_grid1 = B * ((h + 7) / 8) * ((w + 63) / 64);
         RAFT_TRY(launch_conv3x3(wts->convf2, wts->convf2_w, 2, a, EPI_RELU, sf, false, &wts->convf2_w44,
-                                raft_opt(RAFT_OPT_CONVF2_KS, f2_grid1 >= 56 ? 1 : 0)));
+                                raft_opt(RAFT_OPT_CONVF2_KS, f2_grid1 * raft_concurrency() >= 56 ? 1 : 0)));
         RAFT_MARK();
     }
     if (ov) {
@@ -755,7 +755,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
         RAFT_TRY(launch_conv3x3(wts->fh1_mask0, wts->fh1_mask0_w, 8, a, EPI_RELU, s, false, &wts->fh1_mask0_w44));
         RAFT_MARK();
     } else {           // relu(flow_head.conv1(net)) only            3x3, 128 -> 256        -> fm[:, 0:256]
-        const bool w44 = wts->fh1_w44.wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, (int64_t)B * h * w < 2 * 3584 ? 0 : 8) & 8);
+        const bool w44 = wts->fh1_w44.wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, (int64_t)B * h * w * raft_concurrency() < 2 * 3584 ? 0 : 8) & 8);
         ConvArgs a = conv_args(w44 ? wts->fh1_w44 : wts->fh1_w, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 256, fm, 512);
         RAFT_TRY(w44 ? raft_launch_conv_wino4(a, EPI_RELU, s, wts->fh1_mask0_w44.npad) : raft_launch_conv_wino(a, EPI_RELU, s));
     }
@@ -922,6 +922,21 @@ static int enqueue_loop(const raft_basic_update_weights *wts, const LookupSource
                         const raft_state *st, float *flow_up, void *stream, void *aux0, void *aux1, raft_loop_ctx *ctx,
                         bool final_only) {
     hipStream_t s = (hipStream_t)stream;
+    if (aux0 == stream) {
+        // single-stream schedule (aux0 == aux1 == stream): the launches of raft_iterate_basic_f32, for every lookup source and
+        // for the final-only loop -- what several concurrent loops (one per lane of the pipelined forward) run
+        const int64_t up1 = (int64_t)B * 64 * h * w * 2;
+        for (int i = 0; i < iters; ++i) {
+            const bool with_mask = !final_only || i == iters - 1;
+            const bool fused = lookup_is_fused(wts, &src);
+            if (!fused) RAFT_TRY(loop_lookup(src, st, B, h, w, stream));
+            float *up_i = flow_up + (final_only ? 0 : i * up1);
+            const bool mf = with_mask && mask_is_fused(wts, (int64_t)B * h * w);
+            RAFT_TRY(update_basic_impl(wts, B, h, w, st, stream, nullptr, nullptr, with_mask, fused ? &src : nullptr, mf ? up_i : nullptr));
+            if (with_mask && !mf) RAFT_TRY(raft_upsample_convex_f32(st->flow, st->mask, B, h, w, up_i, stream));
+        }
+        return RAFT_OK;
+    }
     Overlap ov = {};
     ov.s1 = (hipStream_t)aux0;
     ov.s2 = (hipStream_t)aux1;
@@ -992,7 +1007,8 @@ static int iterate_basic_overlap_impl(const raft_basic_update_weights *wts, cons
     RAFT_REQUIRE_PTR(ctx);
     RAFT_TRY(check_state(st));
     RAFT_REQUIRE(B > 0 && h > 0 && w > 0 && iters > 0, RAFT_E_SHAPE);
-    RAFT_REQUIRE(aux0 != stream && aux1 != stream && aux0 != aux1, RAFT_E_UNSUPPORTED);
+    // three distinct streams, or all three the same one (the single-stream schedule)
+    RAFT_REQUIRE((aux0 != stream && aux1 != stream && aux0 != aux1) || (aux0 == stream && aux1 == stream), RAFT_E_UNSUPPORTED);
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (!use_loop_graph(B, h, w) || s == nullptr) {   // the legacy NULL stream cannot be captured

@@ -58,7 +58,7 @@ int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s) {
     // channel blocks of 64 per workgroup when that still leaves >= 2 workgroups per CU, else blocks of 32
     const int tiles = a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32);
     const int forced = raft_opt(RAFT_OPT_WINO_TNW, 0);   // tuning / test override (raft_set_option)
-    int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) >= 512) ? 2 : 1;
+    int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) * raft_concurrency() >= 512) ? 2 : 1;
     if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
     const int grid = tiles * (a.npad / (32 * tnw));
     // pinned weight prefetch (SB): always at TNW = 2; at TNW = 1 only when two workgroups per CU hold the whole grid
@@ -69,7 +69,7 @@ int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s) {
     // fewer wave-tasks than SIMDs (grid * 4 < 1024): split K between two wave sets of a 512-thread workgroup
     // (RAFT_WINO_KS = 1 / 2 overrides)
     const bool plain = a.pre_scale == nullptr && a.stats == nullptr;
-    const int ks = raft_opt(RAFT_OPT_WINO_KS, (tnw == 1 && grid <= 224) ? 2 : 1);
+    const int ks = raft_opt(RAFT_OPT_WINO_KS, (tnw == 1 && grid * raft_concurrency() <= 224) ? 2 : 1);
     if (ks == 2 && tnw == 1 && ck2_ok && plain) {
         // 64 channels per stage where the channel counts allow: the stages of these launches are latency, not work
         const bool ck4 = a.c0 % 64 == 0 && a.c1 % 64 == 0 && raft_opt(RAFT_OPT_WINO_CK, 4) == 4;

@@ -53,7 +53,7 @@ int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStrea
         // that leaves about two per CU (gru_q at B = 4 stand-alone: 224 workgroups of 64 channels 28.3 us against 31.0 us
         // for 448 of 32 channels, but inside the three-stream loop with the GRU epilogue 34.5 / 38.6 us against 33.5 / 34.3)
         const int tiles = axis == 0 ? a.B * ((a.H + 1) / 2) * ((a.W + 63) / 64) : a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
-        int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) >= 400) ? 2 : 1;
+        int tnw = (a.npad % 64 == 0 && (int64_t)tiles * (a.npad / 64) * raft_concurrency() >= 400) ? 2 : 1;
         if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
         const int grid = tiles * (a.npad / (32 * tnw));
         if (axis == 0) return tnw == 2 ? launch_wino1d<0, 2, 2, 1, 4>(a, epi, grid, s) : launch_wino1d<0, 1, 2, 1, 4>(a, epi, grid, s);
@@ -61,9 +61,9 @@ int raft_launch_conv_wino1d(const ConvArgs &a, int kh, int kw, int epi, hipStrea
     }
     // F(2, 5): 64-channel workgroups only where that still leaves enough of them (a single 448 x 512 pair: 112 against 448
     // workgroups for gru_zr -- 7.90 -> 7.48 ms per forward with the 32-channel ones, profiles/r06b_b1_options.txt)
-    int tnw = (a.npad % 64 == 0 && (int64_t)tiles_of(2) * (a.npad / 64) >= 400) ? 2 : 1;
+    int tnw = (a.npad % 64 == 0 && (int64_t)tiles_of(2) * (a.npad / 64) * raft_concurrency() >= 400) ? 2 : 1;
     if (forced == 1 || (forced == 2 && a.npad % 64 == 0)) tnw = forced;
-    int tm = (int64_t)tiles_of(2) * (a.npad / (32 * tnw)) >= 400 ? 2 : 1;
+    int tm = (int64_t)tiles_of(2) * (a.npad / (32 * tnw)) * raft_concurrency() >= 400 ? 2 : 1;
     if (tm_forced == 1 || tm_forced == 2) tm = tm_forced;
     const int grid = tiles_of(tm) * (a.npad / (32 * tnw));
     if (axis == 0) return tm == 2 ? launch_wino1d_tm<0, 2>(a, epi, grid, tnw, ck2, s) : launch_wino1d_tm<0, 1>(a, epi, grid, tnw, ck2, s);

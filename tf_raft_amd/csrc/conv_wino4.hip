@@ -25,7 +25,7 @@ int raft_launch_conv_wino4(const ConvArgs &a, int epi, hipStream_t s, int decide
     // like its half of the fused flow / mask head: RAFT.predict_step returns the bits of flow_predictions[-1])
     const int grid_decide = decide_npad > 0 ? grid1 / nt * (decide_npad / 64) : grid1;
     const bool ks2_ok = (a.c0 % 32 == 0) && (a.c1 % 32 == 0);
-    int ks = raft_opt(RAFT_OPT_WINO4_KS, (ks_hint == 1 || ks_hint == 2) ? ks_hint : (grid_decide < 128 ? 2 : 1));
+    int ks = raft_opt(RAFT_OPT_WINO4_KS, (ks_hint == 1 || ks_hint == 2) ? ks_hint : (grid_decide * raft_concurrency() < 128 ? 2 : 1));
     if (ks != 2 || !ks2_ok || a.stats) ks = 1;
     if (a.stats) {   // instance-norm encoder: moments of the raw output, optionally the producer's normalisation + relu on the input
         if (a.pre_scale)

@@ -117,6 +117,16 @@ int opt_index(const char *name) {
 }
 }   // namespace
 
+namespace {
+thread_local int tl_concurrency = 1;
+}
+int raft_concurrency() { return tl_concurrency; }
+extern "C" int raft_set_thread_concurrency(int n) {
+    const int prev = tl_concurrency;
+    tl_concurrency = n < 1 ? 1 : (n > 64 ? 64 : n);
+    return prev;
+}
+
 int raft_opt(int id, int dflt) {
     Options &o = opts();
     return o.set[id].load(std::memory_order_relaxed) ? o.val[id].load(std::memory_order_relaxed) : dflt;

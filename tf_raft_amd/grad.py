@@ -72,6 +72,12 @@ def _is_t(v):
     return isinstance(v, torch.Tensor)
 
 
+def _is_dev_f32(v):
+    """A torch tensor whose data_ptr() may be handed to a HIP kernel as ``const float *``: on the GPU, fp32, contiguous.  Host or
+    other-dtype tensors take the tensor-op packing chain, which converts (or rejects) them in torch."""
+    return isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()
+
+
 def _cat(parts, axis):
     return torch.cat(list(parts), dim=axis) if _is_t(parts[0]) else np.concatenate(list(parts), axis=axis)
 
@@ -335,7 +341,7 @@ def conv2d_backward(x, kernel, dy, y=None, defer=None):
     wino = _wino_kind(kh, kw)
 
     def make_d():
-        if FUSED_TRAIN_PACK and _is_t(kernel):
+        if FUSED_TRAIN_PACK and _is_dev_f32(kernel):
             return _pack_train_device(kernel, None, wino, True, cpad)
         kd = _dgrad_kernel_any(kernel)
         return _pack_conv_any(_wino_transform_any(kd) if wino else kd, None, [(cout, cpad)])
@@ -363,7 +369,7 @@ def _conv_fwd(x, kernel, bias, act=0, scale=1.0):
     cpad = packing.round_up(cin, 32)
     wino = _wino_kind(kh, kw)
     def make():
-        if FUSED_TRAIN_PACK and _is_t(kernel) and (bias is None or _is_t(bias)):
+        if FUSED_TRAIN_PACK and _is_dev_f32(kernel) and (bias is None or _is_dev_f32(bias)):
             return _pack_train_device(kernel, bias, wino, False, cpad)
         return _pack_conv_any(_wino_transform_any(kernel) if wino else kernel, bias, [(cin, cpad)])
     wp_d, b_d, npad = _cached(kernel, 'fwd' + (wino or ''), make, also=bias) if isinstance(bias, (np.ndarray, torch.Tensor)) else make()

@@ -60,13 +60,16 @@ def _dropout_seed(model_seed: int, rank: int, step: int) -> int:
     return int(x >> 2) & ~1
 
 
+DEFAULT_LANES = 3          # profiles/r12b_lanes_ab_per_process.txt: 1 / 2 / 3 / 4 / 6 lanes = 332 / 352 / 362 / 347-352 / 353-362 pairs/s at 4 pairs
+
+
 class RAFT:
     """reference model.py:10-109."""
 
     variant = 'raft'
 
     def __init__(self, drop_rate=0, iters=12, iters_pred=24, weights: Optional[Dict[str, np.ndarray]] = None,
-                 seed=0, alternate_corr=False, overlap=None, pipeline=None, **kwargs):
+                 seed=0, alternate_corr=False, overlap=None, pipeline=None, lanes=None, loop_concurrency=None, **kwargs):
         # reference model.py:11-12 forwards **kwargs to tf.keras.Model, whose constructor takes `name` (and nothing a
         # forward pass depends on): accept it, reject the rest
         self.name = kwargs.pop('name', type(self).__name__.lower())
@@ -81,16 +84,33 @@ class RAFT:
         self.iters = iters
         self.iters_pred = iters_pred
         self.alternate_corr = alternate_corr
-        # three-stream schedule of the loop (RAFT only); RAFT_OVERLAP=0 forces the single-stream loop
-        self.overlap = (os.environ.get('RAFT_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
-        # consecutive inference calls overlap (section "pipelined forward" below); RAFT_PIPELINE=0 restores the serial schedule
-        self.pipeline = (os.environ.get('RAFT_PIPELINE', '1') != '0') if pipeline is None else bool(pipeline)
-        self._aux = None
+        # three-stream schedule of the loop (RAFT only); RAFT_OVERLAP=0 forces the single-stream loop.  With several lanes
+        # (below) the loops of a pipelined call default to the single-stream schedule: the other lanes fill the chain's idle CUs
+        # and gaps better than a loop's own side branches do (profiles/r12b_lanes_ab_per_process.txt).
+        env_ov = os.environ.get('RAFT_OVERLAP')
+        self._overlap_given = overlap is not None or env_ov is not None
+        self.overlap = (env_ov != '0') if overlap is None else bool(overlap)
+        # Consecutive inference calls overlap (section "pipelined forward" below).  OPT-IN (pipeline=True or RAFT_PIPELINE=1):
+        # a pipelined call returns before its loop has finished and its results join the consuming stream lazily, which
+        # consumers that bypass torch's dispatch (C++ extensions taking at::Tensor, the legacy torch.utils.dlpack.to_dlpack)
+        # cannot see -- the default is the serial schedule, where stream order alone makes every route to the bytes safe.
+        # ``predict()`` pipelines regardless: it consumes its own results.
+        self.pipeline = (os.environ.get('RAFT_PIPELINE', '0') == '1') if pipeline is None else bool(pipeline)
+        # Pipelined forward: how many recurrent loops may be in flight at once (each on streams of its own; RAFT_LANES).
+        self.lanes = max(1, int(os.environ.get('RAFT_LANES', str(DEFAULT_LANES))) if lanes is None else int(lanes))
         self._enc_stream = None
         self._state = None
-        self._ring = [None, None]               # pipelined forward: (UpdateState, loop-done event) per slot
+        self._ring = []                          # pipelined forward: [UpdateState, loop-done event] per slot (lanes + 1 slots)
         self._calls = 0
-        self._loop_ctx = None
+        self._lane = 0                           # the lane whose streams / loop context the loop launchers use
+        self._lane_mode = False                  # inside a pipelined call with several lanes and single-stream loops
+        # which launches of a multi-lane call get the library's concurrency hint (launch shapes of a lanes-times larger batch):
+        # 'loop' = the recurrent loop, 'all' = encoders and volume build as well, 'none'
+        self._shape_hint = os.environ.get('RAFT_LANE_SHAPES', 'all')      # profiles/r12e_hint_ab.txt: 361 / 374 / 375 pairs/s with none / loop / all at 4 pairs
+        # serial schedule: the hint its loops are launched with (1 = latency shapes; tests give a serial model the lanes of a
+        # pipelined one to obtain the same kernels, hence the same bits)
+        self.loop_concurrency = 1 if loop_concurrency is None else max(1, int(loop_concurrency))
+        self._lane_res = {}                      # lane -> (device, (flow stream, mask stream), raft_loop_ctx handle)
         self._loop_stream = None
         _dev.require_gpu()
         _dev.lib()
@@ -183,10 +203,27 @@ class RAFT:
                                                 _dev.stream_ptr()), 'prepare_state')
         self.update_block.prepare(st)          # GRU terms of `inp`: constant over the loop (model.py:86)
 
+    @staticmethod
+    def _lane_role(role, lane):
+        return role if lane == 0 else f'{role}{lane}'
+
+    def _loop_priority(self):
+        return -1 if os.environ.get('RAFT_LOOP_PRIORITY', '0') == '1' else 0
+
+    def _lane_entry(self, dev):
+        """(device, (flow stream, mask stream), loop-context handle or None) of the current lane."""
+        ent = self._lane_res.get(self._lane)
+        if ent is None or ent[0] != dev:
+            if ent is not None:
+                self._free_lane(self._lane)
+            prio = self._loop_priority()
+            aux = (_dev.side_stream(dev, self._lane_role('flow', self._lane), prio),
+                   _dev.side_stream(dev, self._lane_role('mask', self._lane), prio))
+            ent = self._lane_res[self._lane] = [dev, aux, None]
+        return ent
+
     def _aux_streams(self, dev):
-        if self._aux is None or self._aux[0].device != dev:
-            self._aux = (_dev.side_stream(dev, 'flow'), _dev.side_stream(dev, 'mask'))
-        return self._aux
+        return self._lane_entry(dev)[1]
 
     @contextlib.contextmanager
     def _capturable_stream(self, dev):
@@ -205,23 +242,28 @@ class RAFT:
         cur.wait_stream(self._loop_stream)   # joined: buffers allocated on `cur` are safe to reuse after this point
 
     def _loop_context(self, dev):
-        """The caller-owned ``raft_loop_ctx`` (cross-stream events + hipGraph cache) of the three-stream loops."""
-        if self._loop_ctx is None or self._loop_ctx[1] != dev:
-            self._free_loop_context()
+        """The caller-owned ``raft_loop_ctx`` (cross-stream events + hipGraph cache) of the three-stream loops: one per lane
+        (loops of different lanes run concurrently; loops of one lane follow each other in stream order and share it)."""
+        ent = self._lane_entry(dev)
+        if ent[2] is None:
             handle = C.c_void_p()
             with torch.cuda.device(dev):
                 check(_dev.lib().raft_loop_ctx_create(C.byref(handle)), 'loop_ctx_create')
-            self._loop_ctx = (handle, dev)
-        return self._loop_ctx[0]
+            ent[2] = handle
+        return ent[2]
 
-    def _free_loop_context(self):
-        if getattr(self, '_loop_ctx', None) is not None:
+    def _free_lane(self, lane):
+        ent = self._lane_res.pop(lane, None)
+        if ent is not None and ent[2] is not None:
             try:
-                torch.cuda.synchronize(self._loop_ctx[1])
-                _dev.lib().raft_loop_ctx_destroy(self._loop_ctx[0])
+                torch.cuda.synchronize(ent[0])
+                _dev.lib().raft_loop_ctx_destroy(ent[2])
             except Exception:   # noqa: BLE001  (interpreter shutdown)
                 pass
-            self._loop_ctx = None
+
+    def _free_loop_context(self):
+        for lane in list(getattr(self, '_lane_res', {})):
+            self._free_lane(lane)
 
     def __del__(self):
         self._free_loop_context()
@@ -230,12 +272,11 @@ class RAFT:
         if self.overlap:
             # flow branch and mask branch of every iteration on two side streams (events inside the library)
             dev = flow_up.device
-            if self._aux is None or self._aux[0].device != dev:
-                self._aux = (_dev.side_stream(dev, 'flow'), _dev.side_stream(dev, 'mask'))
+            aux = self._aux_streams(dev)
             with self._capturable_stream(dev):
                 check(_dev.lib().raft_iterate_basic_overlap_f32(
                     C.byref(self.update_block.c), _dev.ptr(corr._pyr), corr._off, st.B, st.h, st.w, iters, C.byref(st.c),
-                    _dev.ptr(flow_up), _dev.stream_ptr(), self._aux[0].cuda_stream, self._aux[1].cuda_stream,
+                    _dev.ptr(flow_up), _dev.stream_ptr(), aux[0].cuda_stream, aux[1].cuda_stream,
                     self._loop_context(dev)), 'iterate_basic_overlap')
             return
         check(_dev.lib().raft_iterate_basic_f32(C.byref(self.update_block.c), _dev.ptr(corr._pyr), corr._off,
@@ -243,16 +284,17 @@ class RAFT:
                                                 _dev.stream_ptr()), 'iterate_basic')
 
     def _iterate_alternate(self, corr: CorrBlock, st, iters, flow_up):
-        if self.variant == 'raft' and self.overlap:
-            # the same three-stream C loop, lookups computed on demand from fmap1 and the pooled fmap2 pyramid
+        if self.variant == 'raft' and (self.overlap or self._lane_mode):
+            # the same C loop (three streams, or the loop's own stream three times = the single-stream schedule of a lane),
+            # lookups computed on demand from fmap1 and the pooled fmap2 pyramid
             dev = flow_up.device
-            if self._aux is None or self._aux[0].device != dev:
-                self._aux = (_dev.side_stream(dev, 'flow'), _dev.side_stream(dev, 'mask'))
             with self._capturable_stream(dev):
+                s0 = _dev.stream_ptr()
+                s1, s2 = ((a.cuda_stream for a in self._aux_streams(dev)) if self.overlap else (s0, s0))
                 check(_dev.lib().raft_iterate_basic_ondemand_f32(
                     C.byref(self.update_block.c), _dev.ptr(corr.fmap1), _dev.ptr(corr._f2pyr), corr.fmap1.shape[-1],
-                    st.B, st.h, st.w, iters, C.byref(st.c), _dev.ptr(flow_up), _dev.stream_ptr(),
-                    self._aux[0].cuda_stream, self._aux[1].cuda_stream, self._loop_context(dev)), 'iterate_basic_ondemand')
+                    st.B, st.h, st.w, iters, C.byref(st.c), _dev.ptr(flow_up), s0, s1, s2, self._loop_context(dev)),
+                    'iterate_basic_ondemand')
             return
         g = st.g
         for i in range(iters):
@@ -279,7 +321,7 @@ class RAFT:
             self._train_vars, self._dw = keep
             self._inference_stale = False
 
-    def _forward(self, inputs, training=False, final_only=False):
+    def _forward(self, inputs, training=False, final_only=False, pipelined=None):
         self._sync_inference_weights()
         image1, image2 = inputs
         image1 = _dev.to_device(image1)
@@ -290,9 +332,10 @@ class RAFT:
         if H % 8 or W % 8:
             raise ValueError(f'H and W must be multiples of 8 (got {H}x{W})')   # model.py:35 uses h//8
         # model.py:70-71 (2 * (image / 255) - 1) is applied by the encoders while they stage the image
-        if self.pipeline and self.overlap and not training:
+        if (self.pipeline if pipelined is None else pipelined) and not training:
             return self._forward_pipelined(image1, image2, final_only)
         self._join_pipeline()                       # (a training-mode or serial call after pipelined ones)
+        self._lane = 0
         if self.overlap and not training:
             # the context encoder does not depend on the feature encoder or the volume: it runs on a side stream
             # next to them (its one-workgroup-per-CU layers fill the tails of the feature encoder's launches)
@@ -318,7 +361,8 @@ class RAFT:
             st = self._get_state(B, h, w, image1.device)
             self._prepare(cnet, st)                                             # model.py:84-89
         iters = self.iters if training else self.iters_pred
-        out = self._run_loop(correlation, st, iters, self._alloc_out(iters, B, H, W, image1.device, final_only), final_only)
+        with _ffi.thread_concurrency(1 if training else self.loop_concurrency):
+            out = self._run_loop(correlation, st, iters, self._alloc_out(iters, B, H, W, image1.device, final_only), final_only)
         return _dev.wrap(out) if final_only else [_dev.wrap(out[i]) for i in range(iters)]   # model.py:109
 
     @staticmethod
@@ -331,10 +375,12 @@ class RAFT:
         if final_only:
             last = out
             with self._capturable_stream(last.device):
+                # single-stream schedule (several lanes): the flow / mask "branches" are the loop's own stream
+                s0 = _dev.stream_ptr()
+                s1, s2 = ((a.cuda_stream for a in self._aux_streams(last.device)) if self.overlap else (s0, s0))
                 check(_dev.lib().raft_iterate_basic_final_f32(
                     C.byref(self.update_block.c), _dev.ptr(correlation._pyr), correlation._off, B, h, w, iters, C.byref(st.c),
-                    _dev.ptr(last), _dev.stream_ptr(), self._aux_streams(last.device)[0].cuda_stream,
-                    self._aux_streams(last.device)[1].cuda_stream, self._loop_context(last.device)), 'iterate_basic_final')
+                    _dev.ptr(last), s0, s1, s2, self._loop_context(last.device)), 'iterate_basic_final')
             self._last_correlation = correlation
             return last
         flow_up = out
@@ -367,6 +413,8 @@ class RAFT:
                 torch.cuda.current_stream(ent[0].net.device).wait_event(ent[1])
 
     def _ring_state(self, slot, B, h, w, device):
+        while len(self._ring) <= slot:
+            self._ring.append(None)
         ent = self._ring[slot]
         if ent is None or (ent[0].B, ent[0].h, ent[0].w) != (B, h, w) or ent[0].net.device != device:
             if ent is not None and ent[1] is not None:
@@ -374,21 +422,41 @@ class RAFT:
             ent = self._ring[slot] = [UpdateState(self.variant, B, h, w, device), None]
         return ent
 
+    # Several loops in flight (round 6).  The loop's kernels are launched for ONE batch: 7 * 2^k workgroups on 256 CUs, a
+    # ~3 us boundary between dependent kernels, one event gap per iteration -- which is why 8 pairs per call run 9 % and 16 pairs
+    # 17 % faster per pair than 4.  With `lanes` = D > 1 call n's loop runs on lane n % D (loop / flow / mask streams and a
+    # raft_loop_ctx of its own), so up to D loops of consecutive calls are resident together and each fills the other's gaps and
+    # idle CUs; the UpdateState ring has D + 1 slots (call n + D + 1's pre-loop waits for loop n).  Each call still runs exactly
+    # the kernels of the serial schedule in the same order on its own buffers: results stay bit-identical per call.
     def _forward_pipelined(self, image1, image2, final_only):
         B, H, W, _ = image1.shape
         h, w = H // 8, W // 8
         dev = image1.device
         cur = torch.cuda.current_stream(dev)
-        prio = -1 if os.environ.get('RAFT_LOOP_PRIORITY', '0') == '1' else 0
-        loop = _dev.side_stream(dev, 'loop', priority=prio)
-        if self._aux is None or self._aux[0].device != dev:
-            self._aux = (_dev.side_stream(dev, 'flow', priority=prio), _dev.side_stream(dev, 'mask', priority=prio))
-        slot = self._calls & 1
+        lanes = self.lanes
+        n = self._calls
         self._calls += 1
-        ent = self._ring_state(slot, B, h, w, dev)
+        self._lane = lane = n % lanes
+        keep_overlap = self.overlap
+        if lanes > 1 and not self._overlap_given:
+            self.overlap = False                         # single-stream loops: the lanes are each other's side branches
+            self._lane_mode = True
+        try:
+            if lanes > 1 and self._shape_hint == 'all':
+                with _ffi.thread_concurrency(lanes):
+                    return self._forward_lane(image1, image2, final_only, n, lane, lanes, cur, dev, B, H, W, h, w)
+            return self._forward_lane(image1, image2, final_only, n, lane, lanes, cur, dev, B, H, W, h, w)
+        finally:
+            self.overlap = keep_overlap
+            self._lane = 0
+            self._lane_mode = False
+
+    def _forward_lane(self, image1, image2, final_only, n, lane, lanes, cur, dev, B, H, W, h, w):
+        loop = _dev.side_stream(dev, self._lane_role('loop', lane), priority=self._loop_priority())
+        ent = self._ring_state(n % (lanes + 1), B, h, w, dev)
         st = ent[0]
         if ent[1] is not None:
-            cur.wait_event(ent[1])                       # slot's previous user (call n - 2): its loop read this state
+            cur.wait_event(ent[1])                       # slot's previous user (call n - lanes - 1): its loop read this state
         cnet = self.cnet(image1, training=False, _raw_images=True)                      # model.py:82
         self._prepare(cnet, st)                                                          # model.py:84-89
         fmap1, fmap2 = self.fnet([image1, image2], training=False, _raw_images=True)    # model.py:74
@@ -398,7 +466,7 @@ class RAFT:
         ready = torch.cuda.Event()
         ready.record(cur)
         loop.wait_event(ready)
-        with torch.cuda.stream(loop):
+        with torch.cuda.stream(loop), _ffi.thread_concurrency(lanes if self._shape_hint in ('loop', 'all') else 1):
             self._run_loop(correlation, st, self.iters_pred, out, final_only)
             done = torch.cuda.Event()
             done.record(loop)
@@ -411,14 +479,14 @@ class RAFT:
             return _dev.wrap(out, pending)
         return [_dev.wrap(out[i], pending) for i in range(self.iters_pred)]             # model.py:109
 
-    def predict_step(self, data):
+    def predict_step(self, data, _pipelined=None):
         """reference model.py:160-166: ``flow_predictions[-1]`` of the forward pass.  RAFT computes it with the mask head
         and the convex upsampling in the last iteration only (``raft_iterate_basic_final_f32``: the recurrence itself
         is unchanged, so the result equals ``self(...)[-1]``)."""
         image1, image2, *_ = data
         if self.variant == 'raft' and self.overlap and not self.alternate_corr:
-            return self._forward([image1, image2], training=False, final_only=True)
-        return self([image1, image2], training=False)[-1]
+            return self._forward([image1, image2], training=False, final_only=True, pipelined=_pipelined)
+        return self._forward([image1, image2], training=False, pipelined=_pipelined)[-1]
 
     def predict(self, x, batch_size=None, steps=None, **kwargs):
         """``keras.Model.predict`` over ``predict_step`` (reference model.py:160-166): the final flow of every image
@@ -464,7 +532,7 @@ class RAFT:
             filled += got.shape[0]
 
         for i, (image1, image2) in enumerate(prefetch_to_device(batches, buffer_size=1, device=dev)):
-            res = self.predict_step((image1, image2))
+            res = self.predict_step((image1, image2), _pipelined=True)   # consumed below on `down`: the compute stream never waits for a loop
             cur = torch.cuda.current_stream(dev)
             key = (i & 1, tuple(res.shape))
             if key not in pins:
@@ -516,8 +584,9 @@ class RAFT:
         (``tf_raft_amd.grad``: encoders in training form with instance / batch-statistics norms, volume build and its
         backward, the loop and its backward through time; ``tf_raft_amd.training.AdamW``).  With
         ``compile(..., trainable='update_block')`` the encoders stay frozen and run on the inference kernels.
-        The step is orchestrated from Python and re-packs weights on the host for every convolution call: it is the
-        functional path (parity-tested against autograd on the oracle), not yet a tuned one.  RAFT and SmallRAFT."""
+        The step is orchestrated from Python; the updated master weights are re-packed for the kernels ON THE DEVICE, one launch
+        per layer and use (``raft_pack_train_conv_f32``).  It is the functional path (parity-tested against autograd on the
+        oracle), not yet a tuned one.  RAFT and SmallRAFT."""
         from . import grad, losses
         if not hasattr(self, 'flow_metrics'):
             raise RuntimeError('call compile() before train_step()')

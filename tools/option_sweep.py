@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--reps', type=int, default=15)
     ap.add_argument('--shape', default='448x512')
     ap.add_argument('--fresh-model', action='store_true')
+    ap.add_argument('--lanes', type=int, default=0, help='round 6: pipelined forward with this many loops in flight (0: the serial schedule)')
+    ap.add_argument('--overlap', type=int, default=-1, help='with --lanes: 1 / 0 forces three-stream / single-stream loops')
     ap.add_argument('settings', nargs='*')
     a = ap.parse_args()
     H, W = (int(v) for v in a.shape.split('x'))
@@ -37,13 +39,16 @@ def main():
     g = torch.Generator(device=dev).manual_seed(B)
     i1 = torch.rand((B, H, W, 3), device=dev, generator=g) * 255
     i2 = torch.rand((B, H, W, 3), device=dev, generator=g) * 255
-    shared = None if a.fresh_model else tf_raft_amd.RAFT(weights=wts, iters_pred=24)
+    kw = dict(pipeline=True, lanes=a.lanes) if a.lanes else dict(pipeline=False)
+    if a.overlap >= 0:
+        kw['overlap'] = bool(a.overlap)
+    shared = None if a.fresh_model else tf_raft_amd.RAFT(weights=wts, iters_pred=24, **kw)
 
     def run(label, opts):
         for k, v in opts.items():
             _ffi.set_option(k, v)
         try:
-            model = shared or tf_raft_amd.RAFT(weights=wts, iters_pred=24)
+            model = shared or tf_raft_amd.RAFT(weights=wts, iters_pred=24, **kw)
             for _ in range(3):
                 model([i1, i2])
             torch.cuda.synchronize()
