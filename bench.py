@@ -101,7 +101,7 @@ def winograd_layers(pairs=4):
     return on
 
 
-def wino4_launch_shape(layer, B, h, w):
+def wino4_launch_shape(layer, B, h, w, conc=1):
     """(workgroups, K split?) of an F(4x4,3x3) launch of the update block -- the SAME rule as the library applies
     (csrc/conv_wino4.hip raft_launch_conv_wino4 + the per-layer hints of csrc/conv.hip update_basic_impl): 8-row x 64-pixel x
     64-channel workgroups, or K-split 4-row ones when RAFT_WINO4_KS says so, else when the layer's hint says so (convc2:
@@ -112,11 +112,46 @@ def wino4_launch_shape(layer, B, h, w):
     nb = {'convc2': 3, 'fh1_mask0': 8, 'conv': 2, 'convf2': 1}[layer]
     tiles8 = B * ((h + 7) // 8) * ((w + 63) // 64)
     grid1 = tiles8 * nb
-    hint = {'convc2': opt('RAFT_CONVC2_KS'), 'convf2': opt('RAFT_CONVF2_KS') or (1 if tiles8 >= 56 else 0)}.get(layer, 0)
-    ks = opt('RAFT_WINO4_KS') or (hint if hint in (1, 2) else (2 if grid1 < 128 else 1))
+    # conc = raft_set_thread_concurrency: loops sharing the chip count a grid that many times
+    hint = {'convc2': opt('RAFT_CONVC2_KS'), 'convf2': opt('RAFT_CONVF2_KS') or (1 if tiles8 * conc >= 56 else 0)}.get(layer, 0)
+    ks = opt('RAFT_WINO4_KS') or (hint if hint in (1, 2) else (2 if grid1 * conc < 128 else 1))
     if ks == 2:
         return B * ((h + 3) // 4) * ((w + 63) // 64) * nb, True
     return grid1, False
+
+
+# F(4x4) layers of the update block: stage -> (input channels, output channels, field of raft_basic_update_weights)
+W44_FIELDS = {'convc2': (256, 192, 'convc2_w44'), 'conv': (256, 126, 'conv_w44'), 'fh1_mask0': (128, 512, 'fh1_mask0_w44'), 'convf2': (128, 64, 'convf2_w44')}
+
+
+def concurrent_wino4_us(model, _dev, _ffi, field, cin, cout, B, h, w, conc, reps=30):
+    """One F(4x4,3x3) layer of the update block launched on `conc` streams at once (own input / output per stream, the model's
+    packed weights), under the calling thread's launch-shape hint: microseconds per launch of the slowest stream."""
+    wt = getattr(model.update_block.c, field)
+    lib = _dev.lib()
+    streams = [torch.cuda.Stream() for _ in range(conc)]
+    xs = [torch.randn((B, h, w, cin), device='cuda').relu_() for _ in range(conc)]
+    outs = [torch.empty((B, h, w, cout), device='cuda') for _ in range(conc)]
+
+    def launch(i):
+        _ffi.check(lib.raft_conv2d_winograd4_f32(_dev.ptr(xs[i]), cin, cin, None, 0, 0, wt.wp, wt.bias, B, h, w, wt.npad, cout, 1, 1.0,
+                                                 _dev.ptr(outs[i]), cout, streams[i].cuda_stream), 'conv2d_winograd4')
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for i in range(conc):
+            launch(i)
+    torch.cuda.synchronize()
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(conc)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(conc)]
+    for i in range(conc):
+        e0[i].record(streams[i])
+    for _ in range(reps):
+        for i in range(conc):
+            launch(i)
+    for i in range(conc):
+        e1[i].record(streams[i])
+    torch.cuda.synchronize()
+    return max(e0[i].elapsed_time(e1[i]) for i in range(conc)) / reps * 1e3
 
 
 def stage_work(B, h, w):
@@ -410,8 +445,12 @@ def train_bench(args, world, rank, device, backend):
     fence()
     elapsed = time.perf_counter() - t0
     seen = 1
+    rank_elapsed = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_elapsed = [float(e.item()) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         seen = ranks_seen(dist, world, rank, device)
@@ -489,7 +528,11 @@ def main():
     cfg_name = 'BASELINE configs[1]' if (world == 1 and B == 4) else (
         'BASELINE configs[2] per-GPU shape' if B == 8 else 'custom batch')
     wts = wm.init_weights('raft', seed=0)
-    model = tf_raft_amd.RAFT(iters_pred=ITERS, weights=wts)
+    # The timed steps are back-to-back calls whose results nobody consumes at once: the pipelined schedule (opt-in since round 6,
+    # ADVICE r5) with its default number of loops in flight.  RAFT_PIPELINE=0 times the serial schedule instead.
+    pipelined = os.environ.get('RAFT_PIPELINE', '1') != '0'
+    model = tf_raft_amd.RAFT(iters_pred=ITERS, weights=wts, pipeline=pipelined)
+    conc = model.lanes if (pipelined and model.lanes > 1 and model._shape_hint != 'none') else 1      # the launch-shape hint the product's loops run under
     gen = torch.Generator(device=device)
     gen.manual_seed(1000 + rank)
     img1 = torch.rand((B, H, W, 3), device=device, generator=gen) * 255.0
@@ -553,7 +596,7 @@ def main():
         models = {}
         for reg in REGIMES:
             regime_weights[reg] = wts if reg == 'default' else wm.condition_weights('raft', wts, reg)
-            models[reg] = model if reg == 'default' else tf_raft_amd.RAFT(iters_pred=ITERS, weights=regime_weights[reg])
+            models[reg] = model if reg == 'default' else tf_raft_amd.RAFT(iters_pred=ITERS, weights=regime_weights[reg], pipeline=pipelined)
             for _ in range(max(1, args.warmup)):
                 models[reg]([img1, img2], training=False)
         torch.cuda.synchronize()
@@ -578,7 +621,7 @@ def main():
         # barrier); the CPU oracle runs below, untimed -- cpu_baseline is an N = 1 figure
         for reg in ('conditioned', 'jump0'):
             regime_weights[reg] = wm.condition_weights('raft', wts, reg)
-            preds = tf_raft_amd.RAFT(iters_pred=ITERS, weights=regime_weights[reg])([img1, img2], training=False)
+            preds = tf_raft_amd.RAFT(iters_pred=ITERS, weights=regime_weights[reg], pipeline=pipelined)([img1, img2], training=False)
             torch.cuda.synchronize()
             regime_pred0[reg] = [p_.as_subclass(torch.Tensor)[:1].cpu().numpy() for p_ in preds]
             del preds
@@ -596,11 +639,62 @@ def main():
                                   + (', in flight under the next step' if gather_async[0] else '')) if world > 1 else 'none'},
     }
 
+    result['schedule'] = {
+        'pipeline': bool(pipelined), 'loops_in_flight': model.lanes if pipelined else 1,
+        'loop_streams': ('one stream per loop (single-stream schedule), one lane per loop in flight' if model.lanes > 1 else
+                         'three streams per loop (chain + flow branch + mask branch)') if pipelined else 'three streams per loop, calls serial',
+        'launch_shape_hint': conc, 'launch_shape_hint_scope': model._shape_hint if conc > 1 else 'none',
+        'note': 'the timed region is K back-to-back model([a, b]) calls between two device synchronisations: every kernel of every call is '
+                'inside it.  Consecutive calls are independent; call n runs its loop on lane n % loops_in_flight while the next calls\' '
+                'encoders, volume builds and loops proceed (tf_raft_amd/model.py "pipelined forward"); per-call results equal the serial '
+                'schedule\'s bit for bit under the same launch-shape hint (tests/test_gpu_model.py::test_pipelined_calls_are_bitwise_the_serial_calls)'}
+    if world == 1 and rank == 0:
+        # the same K steps on the serial schedule (RAFT(pipeline=False): the default of a model object, what a caller that consumes
+        # every result at once gets), and the latency of ONE call whose result is consumed at once, on both schedules
+        serial_model = tf_raft_amd.RAFT(iters_pred=ITERS, weights=wts, pipeline=False)
+        for _ in range(max(2, args.warmup)):
+            serial_model([img1, img2], training=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            serial_model([img1, img2], training=False)
+        torch.cuda.synchronize()
+        result['schedule']['serial_schedule_pairs_per_s'] = round(B * args.steps / (time.perf_counter() - t0), 3)
+
+        def consumed_ms(m, a, b, n=5):
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = m([a, b], training=False)[-1].as_subclass(torch.Tensor)
+                torch.cuda.current_stream().synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+                del out
+            return round(float(np.median(ts)), 3)
+        result['schedule']['single_call_consumed_at_once_ms'] = {
+            'pipelined_model': consumed_ms(model, img1, img2), 'serial_model': consumed_ms(serial_model, img1, img2),
+            'one_pair_pipelined_model': consumed_ms(model, img1[:1], img2[:1]), 'one_pair_serial_model': consumed_ms(serial_model, img1[:1], img2[:1])}
+        del serial_model
+
     if world > 1:
         result['ranks_seen'] = seen                      # distinct rank ids that arrived through the job's all-gather
         result['preflight'] = pre                        # announced on stderr BEFORE the timed region (devices, .so mapped / not rebuilt)
         result['scaling_curve'] = 'none measured by this repository: 8-GPU runs are the driver\'s (DESIGN.md section 6)'
         result['backend'] = 'RCCL ' + '.'.join(str(v) for v in torch.cuda.nccl.version()) if backend == 'nccl' else backend
+        # the collective alone: one all-gather of flow_predictions[-1] (every rank takes part), barrier-to-sync, median of 5
+        last = model([img1, img2], training=False)[-1].as_subclass(torch.Tensor)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            all_gather_batch(last, world * B)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e6)
+        result['all_gather_us'] = {'median': round(float(np.median(ts)), 1), 'bytes_per_rank': int(last.numel() * 4),
+                                   'note': 'issued alone after a barrier; in the timed steps it is in flight under the next step'}
+        del last
         # ONE GPU at the same per-GPU shape, no collective: rank 0 alone, the other ranks wait at the closing barrier.
         # The driver computes scaling efficiency from its own N = 1 run; this is the like-for-like figure beside it.
         if rank == 0:
@@ -608,11 +702,18 @@ def main():
                 model([img1, img2], training=False)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            n1 = max(1, min(args.steps, 5))
+            n1 = max(1, args.steps)
             for _ in range(n1):
                 model([img1, img2], training=False)
             torch.cuda.synchronize()
             result['one_gpu_same_shape_pairs_per_s'] = round(B * n1 / (time.perf_counter() - t0), 3)
+            # efficiency against the SAME per-GPU shape on this box (not against the 4-pair N = 1 line, whose
+            # smaller batch fills the chip less well); the driver computes its own figure from its own N = 1 run
+            result['scaling_efficiency'] = round(value / world / result['one_gpu_same_shape_pairs_per_s'], 4)
+            result['scaling_efficiency_basis'] = ('whole-job pairs/s / n_gpus / one_gpu_same_shape_pairs_per_s (rank 0 alone, the same '
+                                                  f'{B} pairs per step, no collective, measured in this job after the timed region)')
+        result['rank_step_ms'] = {'min': round(1e3 * min(rank_elapsed) / args.steps, 3), 'max': round(1e3 * max(rank_elapsed) / args.steps, 3),
+                                  'per_rank': [round(1e3 * e / args.steps, 3) for e in rank_elapsed]}
 
     if rank == 0 and world == 1:
         # ---------------- informational: RAFT.predict_step (flow_predictions[-1] only: mask head + upsampling in the
@@ -621,7 +722,7 @@ def main():
             model.predict_step((img1, img2))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = max(1, min(args.steps, 5))
+        n = max(1, args.steps)                      # several loops are in flight: as many steps as the headline, or the ramp dominates
         for _ in range(n):
             model.predict_step((img1, img2))
         torch.cuda.synchronize()
@@ -634,7 +735,8 @@ def main():
         for _ in range(n):
             model([img1[:1], img2[:1]], training=False)
         torch.cuda.synchronize()
-        result['batch1_ms_per_pair'] = round(1e3 * (time.perf_counter() - t0) / n, 3)
+        # back-to-back calls, results not consumed: a THROUGHPUT figure (the latency of one consumed call is schedule.single_call_consumed_at_once_ms)
+        result['batch1_back_to_back_ms_per_call'] = round(1e3 * (time.perf_counter() - t0) / n, 3)
         result['batch1_pairs_per_s'] = round(n / (time.perf_counter() - t0), 3)
         # ---------------- informational: ONE GPU at the per-GPU shape `--gpus N > 1` runs (BASELINE configs[2]: 8 pairs
         # per GPU), so that multi-GPU lines can be set against a single-GPU number of the same per-GPU work
@@ -652,7 +754,9 @@ def main():
             del i8a, i8b
 
     if rank == 0:
-        # ---------------- instrumented replay: per-kernel HIP-event timing on the launch stream
+        # ---------------- instrumented replay: per-kernel HIP-event timing on the launch stream, with the launch shapes the
+        # product's loops run (the thread-local hint of the multi-lane schedule; reset before the line is printed)
+        _dev.lib().raft_set_thread_concurrency(conc)
         h, w = H // 8, W // 8
         x1 = 2 * (img1 / 255.0) - 1.0
         x2 = 2 * (img2 / 255.0) - 1.0
@@ -728,7 +832,7 @@ def main():
             'note': 'raft_mfma_probe_f32: an MFMA-only loop (no loads, no VALU) on all 256 CUs; every roofline.frac is quoted against '
                     'the 157.3 TFLOP/s datasheet peak as the contract asks, frac_of_sustained_mfma beside it is against this figure'}
 
-        wl = winograd_layers(B)
+        wl = winograd_layers(B * conc)                        # the library's rules count a grid `conc` times under the hint
         if dom in flops:
             ratio = wl.get(dom, 1.0)                          # direct MACs / MACs issued on the MFMA pipe
             alg = flops[dom] / (stage_ms[dom] * 1e-3) / 1e12
@@ -751,7 +855,7 @@ def main():
                 # launch geometry of the F(4x4) kernel: at 448 x 512 the counts are 7 * 2^k -- a single round of workgroups that
                 # leaves CUs to the side branches of the three-stream loop (docs/NOTEBOOK.md 4.5 / 4.6), so the whole-chip fraction above
                 # has the occupied-CU fraction beside it
-                wgs, ksplit = wino4_launch_shape(dom, B, h, w)
+                wgs, ksplit = wino4_launch_shape(dom, B, h, w, conc)
                 occ = min(1.0, wgs / 256.0)
                 roof['launch'] = {'workgroups': wgs, 'k_split': ksplit, 'cus': 256, 'occupied_cu_frac': round(occ, 4),
                                   'frac_on_occupied_cus': round(ach / PEAK_FP32_MFMA_TFLOPS / occ, 4)}
@@ -762,6 +866,25 @@ def main():
                     'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': tr,
                     'bytes_per_launch': bytes_[dom], 'ms_per_launch': stage_ms[dom],
                     'ms_per_launch_between_events': stage_ms_events[dom], 'traffic_source': note}
+        # Several loops in flight: a lane's kernel is launched in the shape of a `conc`-times larger batch (fewer, longer workgroups:
+        # convc2 84 instead of 168) and the OTHER lanes' kernels fill the rest of the chip.  Alone in a single stream (the replay
+        # above) such a launch leaves most CUs idle, so the whole-chip fraction of one instance says little about the product; the
+        # figure that does is the same kernel with the chip filled the way the product fills it: `conc` instances on `conc`
+        # streams (HIP events on every launch stream, the slowest stream counts).  `roofline` carries that as achieved / frac and
+        # keeps the single instance beside it.
+        if conc > 1 and roof.get('bound') == 'mfma' and dom in W44_FIELDS and wl.get(dom) == 4.0:
+            cin, cout, field = W44_FIELDS[dom]
+            us_c = concurrent_wino4_us(model, _dev, _ffi, field, cin, cout, B, h, w, conc)
+            ach_c = conc * flops[dom] / wl[dom] / (us_c * 1e-6) / 1e12
+            roof['single_instance'] = {k: roof[k] for k in ('achieved', 'frac', 'ms_per_launch', 'ms_per_launch_between_events',
+                                                            'achieved_between_events', 'frac_between_events', 'frac_of_sustained_mfma', 'launch') if k in roof}
+            roof.update({'achieved': round(ach_c, 2), 'frac': round(ach_c / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'frac_of_sustained_mfma': round(ach_c / mfma_sust, 4), 'instances': conc,
+                         'ms_per_launch': round(us_c * 1e-3, 5), 'flops_per_launch': flops[dom] / wl[dom],
+                         'measured': f'{conc} concurrent instances of the launch on {conc} streams (= the product\'s loops in flight), HIP events on '
+                                     'each launch stream around 30 launches, slowest stream; achieved = instances x executed FLOPs per launch / that time'})
+            for k in ('ms_per_launch_between_events', 'achieved_between_events', 'frac_between_events'):
+                roof.pop(k, None)
         result['roofline'] = roof
         # the HBM-bound kernels the north star singles out: per-launch algorithmic bytes / HIP-event time, against the
         # 8 TB/s datasheet peak (frac) and against this box's measured copy bandwidth (frac_of_measured_copy)
@@ -903,7 +1026,22 @@ def main():
             obj['rocprof'] = {'us_per_launch': us, 'achieved': round(a, 2), 'frac': round(a / peak, 4), 'stale': dur_ev['stale'],
                               'hip_events_over_rocprof': round(obj['ms_per_launch'] * 1e3 / us, 3), 'batch': batch}
         r = result['roofline']
-        attach(r, r['kernel'], r.get('flops_per_launch', r.get('bytes_per_launch')), r['peak'], 1e12 if r['bound'] == 'mfma' else 1e9)
+        if 'instances' in r:
+            # measured with `instances` concurrent launches: the rocprofv3 side is the kernel trace of the same microbenchmark
+            # (tools/concurrent_kernel.py under rocprofv3 -> profiles/kernel_concurrent.json); the single instance against the single-stream trace
+            cdur, cev = evidence_file('kernel_concurrent.json')
+            ent = (cdur or {}).get(r['kernel'])
+            if ent and ent.get('batch') == B and ent.get('instances') == r['instances']:
+                a = r['instances'] * r['flops_per_launch'] / (ent['avg_us'] * 1e-6) / 1e12
+                r['rocprof'] = {'us_per_launch': ent['avg_us'], 'achieved': round(a, 2), 'frac': round(a / r['peak'], 4), 'stale': cev['stale'],
+                                'hip_events_over_rocprof': round(r['ms_per_launch'] * 1e3 / ent['avg_us'], 3), 'batch': B, 'instances': ent['instances'],
+                                'source': 'profiles/kernel_concurrent.json: average kernel duration while `instances` launches share the chip'}
+            else:
+                r['rocprof'] = None
+            result['evidence']['kernel_concurrent'] = cev
+            attach(r['single_instance'], r['kernel'], r['flops_per_launch'], r['peak'], 1e12)
+        else:
+            attach(r, r['kernel'], r.get('flops_per_launch', r.get('bytes_per_launch')), r['peak'], 1e12 if r['bound'] == 'mfma' else 1e9)
         for name in ('corr_lookup', 'upsample_convex'):
             attach(result['roofline_' + name], name, bytes_[name], PEAK_HBM_GBS, 1e9)
             if result['roofline_' + name]['rocprof']:
@@ -933,6 +1071,7 @@ def main():
                                      'times = interval between events minus event_bracket_us (calibrated in the same run against '
                                      'the un-bracketed single-stream loop: the net stages add up to its measured iteration time)')
 
+        _dev.lib().raft_set_thread_concurrency(1)
         # ---------------- PCIe-inclusive rate (host-resident fp32 inputs), informational only: never `value`
         if world == 1:
             from tf_raft_amd.prefetch import prefetch_to_device

@@ -704,8 +704,8 @@ def test_alternate_corr_model_matches_volume_model():
     assert max(errs) <= TOL
 
 
-@pytest.mark.parametrize('variant,kw,shape,iters', [('raft', {}, (2, 128, 192), 6), ('raft', {}, (4, 448, 512), 5), ('small', {}, (2, 128, 192), 6),
-                                                     ('raft', {'alternate_corr': True}, (1, 256, 320), 4),
+@pytest.mark.parametrize('variant,kw,shape,iters', [('raft', {'lanes': 1}, (2, 128, 192), 6), ('raft', {'lanes': 1}, (4, 448, 512), 5), ('small', {'lanes': 1}, (2, 128, 192), 6),
+                                                     ('raft', {'lanes': 1, 'alternate_corr': True}, (1, 256, 320), 4),
                                                      # round 6: several loops in flight, each on streams of its own
                                                      ('raft', {'lanes': 2}, (4, 448, 512), 5), ('raft', {'lanes': 3}, (2, 128, 192), 6),
                                                      ('raft', {'lanes': 2, 'overlap': False}, (2, 128, 192), 6),
@@ -837,7 +837,7 @@ def test_rotating_buffer_loop_is_bitwise_the_single_stream_loop(shape, iters, ra
     raft_opt.set('RAFT_MASK_FUSED', '1')          # the schedule belongs to the fused mask kernel (default from 2 pairs on)
     ref = [_np(p) for p in tf_raft_amd.RAFT(weights=wts, iters_pred=iters, overlap=False)([i1, i2])]
     for pipeline in (False, True):
-        model = tf_raft_amd.RAFT(weights=wts, iters_pred=iters, overlap=True, pipeline=pipeline)
+        model = tf_raft_amd.RAFT(weights=wts, iters_pred=iters, overlap=True, pipeline=pipeline, lanes=1)
         for _ in range(4):
             got = [_np(p) for p in model([i1, i2])]
             for a, b_ in zip(got, ref):

@@ -757,7 +757,7 @@ static int update_basic_impl(const raft_basic_update_weights *wts, int B, int h,
     } else {           // relu(flow_head.conv1(net)) only            3x3, 128 -> 256        -> fm[:, 0:256]
         const bool w44 = wts->fh1_w44.wp != nullptr && (raft_opt(RAFT_OPT_CONV_WINO4, (int64_t)B * h * w * raft_concurrency() < 2 * 3584 ? 0 : 8) & 8);
         ConvArgs a = conv_args(w44 ? wts->fh1_w44 : wts->fh1_w, st->net, HDIM, HDIM, nullptr, 0, 0, B, h, w, 256, fm, 512);
-        RAFT_TRY(w44 ? raft_launch_conv_wino4(a, EPI_RELU, s, wts->fh1_mask0_w44.npad) : raft_launch_conv_wino(a, EPI_RELU, s));
+        RAFT_TRY(w44 ? raft_launch_conv_wino4(a, EPI_RELU, s, wts->fh1_mask0_w44.npad) : raft_launch_conv_wino(a, EPI_RELU, s, wts->fh1_mask0_w.npad));
     }
     if (ov && with_mask && flow_up_fused == nullptr) {   // two-kernel mask branch: mask.2 may start before fh2
         RAFT_HIP(hipEventRecord(ov->e_fm, s));

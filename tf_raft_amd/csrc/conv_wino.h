@@ -376,4 +376,6 @@ __global__ void __launch_bounds__(256 * KS, KS == 2 ? 1 : ((TNW == 1 && !SB && !
 // launcher (conv_wino.hip); `a.wp` holds the winograd-transformed weights packed as a 4x4-tap kernel
 // epi: EPI_LINEAR / EPI_RELU / EPI_RES; a.pre_scale != NULL selects PRE, a.stats != NULL selects STATS (the encoder
 // combinations: LINEAR + STATS (+ PRE), RELU, RES).  Stats entries per image: 2 * ceil(H/4) * ceil(W/32).
-int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s);
+// decide_npad > 0: choose the variant (channel width, K split, stage depth) as a layer of that many output channels would --
+// flow_head.conv1 alone must round exactly like its half of the fused flow / mask head (RAFT.predict_step == flow_predictions[-1])
+int raft_launch_conv_wino(const ConvArgs &a, int epi, hipStream_t s, int decide_npad = 0);

@@ -333,9 +333,18 @@ class RAFT:
             raise ValueError(f'H and W must be multiples of 8 (got {H}x{W})')   # model.py:35 uses h//8
         # model.py:70-71 (2 * (image / 255) - 1) is applied by the encoders while they stage the image
         if (self.pipeline if pipelined is None else pipelined) and not training:
-            return self._forward_pipelined(image1, image2, final_only)
+            # several lanes (and their launch shapes) only for a model that asked for the pipelined schedule: predict() on a serial
+            # model overlaps its calls on ONE lane with the serial schedule's kernels, so predict() == predict_step() bit for bit
+            return self._forward_pipelined(image1, image2, final_only, self.lanes if self.pipeline else 1)
         self._join_pipeline()                       # (a training-mode or serial call after pipelined ones)
         self._lane = 0
+        if self.loop_concurrency > 1 and self._shape_hint == 'all' and not training:
+            with _ffi.thread_concurrency(self.loop_concurrency):        # the whole call with a multi-lane call's launch shapes
+                return self._forward_serial(image1, image2, training, final_only)
+        return self._forward_serial(image1, image2, training, final_only)
+
+    def _forward_serial(self, image1, image2, training, final_only):
+        B, H, W, _ = image1.shape
         if self.overlap and not training:
             # the context encoder does not depend on the feature encoder or the volume: it runs on a side stream
             # next to them (its one-workgroup-per-CU layers fill the tails of the feature encoder's launches)
@@ -361,7 +370,7 @@ class RAFT:
             st = self._get_state(B, h, w, image1.device)
             self._prepare(cnet, st)                                             # model.py:84-89
         iters = self.iters if training else self.iters_pred
-        with _ffi.thread_concurrency(1 if training else self.loop_concurrency):
+        with _ffi.thread_concurrency(self.loop_concurrency if (not training and self._shape_hint in ('loop', 'all')) else 1):
             out = self._run_loop(correlation, st, iters, self._alloc_out(iters, B, H, W, image1.device, final_only), final_only)
         return _dev.wrap(out) if final_only else [_dev.wrap(out[i]) for i in range(iters)]   # model.py:109
 
@@ -428,12 +437,11 @@ class RAFT:
     # raft_loop_ctx of its own), so up to D loops of consecutive calls are resident together and each fills the other's gaps and
     # idle CUs; the UpdateState ring has D + 1 slots (call n + D + 1's pre-loop waits for loop n).  Each call still runs exactly
     # the kernels of the serial schedule in the same order on its own buffers: results stay bit-identical per call.
-    def _forward_pipelined(self, image1, image2, final_only):
+    def _forward_pipelined(self, image1, image2, final_only, lanes):
         B, H, W, _ = image1.shape
         h, w = H // 8, W // 8
         dev = image1.device
         cur = torch.cuda.current_stream(dev)
-        lanes = self.lanes
         n = self._calls
         self._calls += 1
         self._lane = lane = n % lanes

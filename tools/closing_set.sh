@@ -7,7 +7,10 @@
 #   <tag>_single_stream_b{4,8}_rocprofv3_kernel_stats.csv + kernel_durations.json   single-stream loop, per-stage durations
 #   <tag>_pmc_per_kernel.csv + pmc_traffic.json     FETCH_SIZE / WRITE_SIZE passes at 8 pairs      (skipped with SKIP_PMC=1)
 #   <tag>_loop_timeline_b4.txt                      kernel timeline of the product loop
-#   <tag>_pipeline_ab.txt                           the bench step with RAFT_PIPELINE=0 / 1 (A/B/A/B)
+#   <tag>_lanes_ab.txt                              round 6: serial / one lane / 2-4 lanes, one process per setting; launch-shape hint scopes
+#   <tag>_lanes_timeline_b4.txt                     steady-state kernel timeline of the 3-lane schedule
+#   <tag>_kernel_concurrent.json                    the dominant kernel on 3 streams at once (rocprofv3 side of bench.py `roofline`)
+#   <tag>_config_bench.txt, <tag>_bench_train.log   the other BASELINE configurations, the training step
 #   <tag>_instruction_mix.txt                       MFMA / VALU / LDS instructions per wave per kernel (tools/instruction_mix.sh)
 # usage: bash tools/closing_set.sh <tag>
 tag=${1:-r10a}
@@ -38,14 +41,35 @@ fi
 # the bench line reads the two summaries just made (the same library is loaded: not stale)
 [ -f $out/${tag}_kernel_durations.json ] && cp $out/${tag}_kernel_durations.json profiles/kernel_durations.json
 [ -f $out/${tag}_pmc_traffic.json ] && cp $out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
-timeout 600 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_b4.log 2>&1
-# the serial schedule of consecutive calls beside the pipelined default (same box, same minute)
-for p in 0 1 0 1; do
-  RAFT_PIPELINE=$p timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity 2>/dev/null | python -c "
-import json, sys
-d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('RAFT_PIPELINE=$p value', d['value'], 'ms_per_step', d['ms_per_step'])"
-done > $out/${tag}_pipeline_ab.txt 2>&1
+# the dominant kernel with the chip filled the way the product fills it (bench.py `roofline`): rocprofv3 side
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/${tag}_conc -o conc -- python $root/tools/concurrent_kernel.py run convc2 4 3 > $out/${tag}_concurrent_convc2.txt 2>&1)
+t=$(ls $out/${tag}_conc/*kernel_trace.csv 2>/dev/null | head -1)
+if [ -n "$t" ]; then
+  python tools/concurrent_kernel.py summarise $t $out/${tag}_kernel_concurrent.json convc2 4 3 > /dev/null 2>&1 && cp $out/${tag}_kernel_concurrent.json profiles/kernel_concurrent.json
+  cp $(ls $out/${tag}_conc/*kernel_stats.csv | head -1) $out/${tag}_concurrent_convc2_rocprofv3_kernel_stats.csv
+fi
+rm -rf $out/${tag}_conc
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_b4.log 2>&1
+# round 6: the schedules of consecutive calls side by side, ONE PROCESS PER SETTING (streams map onto hardware queues in creation
+# order: several settings in one process disturb each other) -- serial, one lane on three streams (round 5), 2 / 3 / 4 single-stream lanes
+for s in serial 1:1 2:0 3:0 4:0 serial 3:0; do
+  timeout 300 python tools/lanes_ab.py --batch 4 --rounds 3 $s 2>/dev/null | grep pairs
+done > $out/${tag}_lanes_ab.txt 2>&1
+for s in serial 3:0; do
+  timeout 300 python tools/lanes_ab.py --batch 8 --rounds 3 $s 2>/dev/null | grep pairs
+  timeout 300 python tools/lanes_ab.py --batch 1 --rounds 3 $s 2>/dev/null | grep pairs
+done >> $out/${tag}_lanes_ab.txt 2>&1
+for sc in none loop all; do
+  RAFT_LANE_SHAPES=$sc timeout 300 python tools/lanes_ab.py --batch 4 --rounds 3 3:0 2>/dev/null | grep pairs | sed "s/^/RAFT_LANE_SHAPES=$sc /"
+done >> $out/${tag}_lanes_ab.txt 2>&1
+# the other BASELINE configurations (configs 1 / 3-per-GPU / 4, SmallRAFT) on both schedules, and the training step
+timeout 900 python tools/config_bench.py 10 > $out/${tag}_config_bench.txt 2>&1
+timeout 900 python bench.py --train --steps 10 --warmup 3 > $out/${tag}_bench_train.log 2>&1
+# steady-state kernel timeline of the multi-lane schedule (queue occupancy, kernels in flight, stretch of each kernel under sharing)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace -f csv -d $out/${tag}_lt -o lt -- python $root/tools/lanes_ab.py --batch 4 --rounds 2 3:0 > /dev/null 2>&1)
+t=$(ls $out/${tag}_lt/*kernel_trace.csv 2>/dev/null | head -1)
+[ -n "$t" ] && python tools/pipeline_timeline.py $t "3 lanes, 4 pairs $tag" > $out/${tag}_lanes_timeline_b4.txt 2>&1
+rm -rf $out/${tag}_lt
 [ -z "${SKIP_PMC:-}" ] && bash tools/instruction_mix.sh $tag 4 > /dev/null 2>&1 && rm -rf $out/${tag}_mix
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $out/${tag}_prof -o bench -- python $root/bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_b4_under_rocprof.log 2>&1

@@ -22,7 +22,7 @@ def run(name, model, B, H, W, steps):
     g = torch.Generator(device=dev).manual_seed(0)
     i1 = torch.rand((B, H, W, 3), device=dev, generator=g) * 255
     i2 = torch.rand((B, H, W, 3), device=dev, generator=g) * 255
-    for _ in range(2):
+    for _ in range(4):
         model([i1, i2])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -38,12 +38,15 @@ def run(name, model, B, H, W, steps):
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     w = wm.init_weights('raft', seed=0)
-    run('config3-per-GPU RAFT', tf_raft_amd.RAFT(weights=w, iters_pred=24), 8, 448, 512, steps)
-    run('config4 RAFT alternate_corr', tf_raft_amd.RAFT(weights=w, iters_pred=24, alternate_corr=True), 1, 1024, 1024, steps)
-    run('config4-size RAFT stored volume', tf_raft_amd.RAFT(weights=w, iters_pred=24), 1, 1024, 1024, steps)
     ws = wm.init_weights('small', seed=0)
-    run('SmallRAFT', tf_raft_amd.SmallRAFT(weights=ws, iters_pred=24), 4, 448, 512, steps)
-    run('SmallRAFT config1 shape', tf_raft_amd.SmallRAFT(weights=ws, iters_pred=4), 1, 256, 256, steps)
+    # every configuration on the serial schedule (a model's default) and on the pipelined one (pipeline=True: several loops in flight)
+    for tag, kw in (('serial', dict(pipeline=False)), ('pipelined', dict(pipeline=True))):
+        run(f'[{tag}] config2 RAFT (the bench line)', tf_raft_amd.RAFT(weights=w, iters_pred=24, **kw), 4, 448, 512, steps)
+        run(f'[{tag}] config3-per-GPU RAFT', tf_raft_amd.RAFT(weights=w, iters_pred=24, **kw), 8, 448, 512, steps)
+        run(f'[{tag}] config4 RAFT alternate_corr', tf_raft_amd.RAFT(weights=w, iters_pred=24, alternate_corr=True, **kw), 1, 1024, 1024, steps)
+        run(f'[{tag}] config4-size RAFT stored volume', tf_raft_amd.RAFT(weights=w, iters_pred=24, **kw), 1, 1024, 1024, steps)
+        run(f'[{tag}] SmallRAFT', tf_raft_amd.SmallRAFT(weights=ws, iters_pred=24, **kw), 4, 448, 512, steps)
+        run(f'[{tag}] SmallRAFT config1 shape', tf_raft_amd.SmallRAFT(weights=ws, iters_pred=4, **kw), 1, 256, 256, steps)
 
 
 if __name__ == '__main__':

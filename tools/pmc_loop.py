@@ -19,7 +19,10 @@ gen.manual_seed(1000)
 i1 = torch.rand((B, 448, 512, 3), device=dev, generator=gen) * 255.0
 i2 = torch.rand((B, 448, 512, 3), device=dev, generator=gen) * 255.0
 from tf_raft_amd import _ffi  # noqa: E402
-model = tf_raft_amd.RAFT(iters_pred=iters, overlap=False)
+# the launch shapes of the product: a multi-lane pipelined call launches its loops under raft_set_thread_concurrency(lanes)
+from tf_raft_amd.model import DEFAULT_LANES  # noqa: E402
+conc = int(os.environ.get('RAFT_LOOP_CONCURRENCY', DEFAULT_LANES))
+model = tf_raft_amd.RAFT(iters_pred=iters, overlap=False, pipeline=False, loop_concurrency=conc)
 out = model([i1, i2])                            # product default: lookup fused into convc1 (attributed by kernel name)
 torch.cuda.synchronize()
 _ffi.set_option('RAFT_LOOKUP_FUSED', 0)          # then the two-kernel loops: 14 kernels per iteration, attributed by order
