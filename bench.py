@@ -445,12 +445,8 @@ def train_bench(args, world, rank, device, backend):
     fence()
     elapsed = time.perf_counter() - t0
     seen = 1
-    rank_elapsed = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        every = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(every, t)
-        rank_elapsed = [float(e.item()) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         seen = ranks_seen(dist, world, rank, device)
@@ -582,8 +578,12 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_elapsed = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_elapsed = [float(e.item()) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * B * args.steps / elapsed

@@ -48,8 +48,8 @@
  *   RAFT_CONVC2_KS      1/2  convc2 on the F(4x4) kernel in the loops: 8-row workgroups / K-split 4-row workgroups   (default: by grid size)
  *   RAFT_CONVF2_KS      1/2  the same for convf2                             (default: K-split below 56 eight-row workgroups)
  *   RAFT_EVENT_FENCE    0/1  cross-stream events of a raft_loop_ctx without / with the system-scope fence of a default HIP event
- *                            (read when the context is created)                                    (default 0: the events
- *                            only order streams of one device; +0.4 .. 0.9 %, profiles/r10c_event_fence.txt)
+ *                            (read when the context is created)                                    (default 1 since round 6; 0: the
+ *                            events only order streams of one device, +0.4 .. 0.9 % on the three-stream loop, profiles/r10c_event_fence.txt)
  *   RAFT_CORR_XCD       0/1/n  volume build: plain (n, m, batch) tile grid / one region of the tile plane per XCD, walked in strips
  *                            of 2 (n >= 2: n) column tiles                                          (default 1)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)

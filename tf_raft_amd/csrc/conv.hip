@@ -852,13 +852,13 @@ extern "C" int raft_loop_ctx_create(raft_loop_ctx **out) {
     if (!c) return (int)hipErrorOutOfMemory;
     int rc = (int)hipGetDevice(&c->device);
     int made = 0;
-    // The events order streams of ONE device, so they are created without the system-scope release / acquire that a default
-    // HIP event performs when it completes (hipEventDisableSystemFence): kernel boundaries still release / acquire at agent
-    // scope, which is what consecutive kernels of one stream rely on too; host and peer visibility of the results comes from
-    // the caller's stream synchronisation, not from these events.  329.8 against 326.3 - 327.0 pairs/s at 4 pairs, 358.8
-    // against 357.1 - 357.6 at 8 (A/B/A in one process, profiles/r10c_event_fence.txt); RAFT_EVENT_FENCE=1 restores the fence
-    // (read once, when the context is created).
-    const unsigned flags = hipEventDisableTiming | (raft_opt(RAFT_OPT_EVENT_FENCE, 0) ? 0u : (unsigned)hipEventDisableSystemFence);
+    // Default HIP events (system-scope release / acquire when they complete).  The events only order streams of ONE device and
+    // kernel boundaries release / acquire at agent scope anyway, so RAFT_EVENT_FENCE=0 creates them with
+    // hipEventDisableSystemFence: +0.4 .. 0.9 % on the three-stream loop (329.8 against 326.3 - 327.0 pairs/s at 4 pairs, A/B/A in
+    // one process, profiles/r10c_event_fence.txt), validated by the bitwise three-stream tests only -- since round 6 an opt-in:
+    // the throughput schedule (several single-stream loops in flight) has no event inside the loop, so the default costs it nothing.
+    // Read once, when the context is created.
+    const unsigned flags = hipEventDisableTiming | (raft_opt(RAFT_OPT_EVENT_FENCE, 1) ? 0u : (unsigned)hipEventDisableSystemFence);
     for (; made < 4 && rc == RAFT_OK; ++made) rc = (int)hipEventCreateWithFlags(&c->ev[made], flags);
     if (rc != RAFT_OK) {
         for (int k = 0; k < made - 1; ++k) (void)hipEventDestroy(c->ev[k]);
