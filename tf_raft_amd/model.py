@@ -451,13 +451,19 @@ class RAFT:
             self._lane_mode = True
         try:
             if lanes > 1 and self._shape_hint == 'all':
-                with _ffi.thread_concurrency(lanes):
+                with _ffi.thread_concurrency(self._hint_value(lanes)):
                     return self._forward_lane(image1, image2, final_only, n, lane, lanes, cur, dev, B, H, W, h, w)
             return self._forward_lane(image1, image2, final_only, n, lane, lanes, cur, dev, B, H, W, h, w)
         finally:
             self.overlap = keep_overlap
             self._lane = 0
             self._lane_mode = False
+
+    @staticmethod
+    def _hint_value(lanes):
+        """The launch-shape hint of a multi-lane call: the number of loops that share the chip (RAFT_LANE_HINT overrides, for A/B runs)."""
+        v = os.environ.get('RAFT_LANE_HINT')
+        return max(1, int(v)) if v else lanes
 
     def _forward_lane(self, image1, image2, final_only, n, lane, lanes, cur, dev, B, H, W, h, w):
         loop = _dev.side_stream(dev, self._lane_role('loop', lane), priority=self._loop_priority())
@@ -474,7 +480,7 @@ class RAFT:
         ready = torch.cuda.Event()
         ready.record(cur)
         loop.wait_event(ready)
-        with torch.cuda.stream(loop), _ffi.thread_concurrency(lanes if self._shape_hint in ('loop', 'all') else 1):
+        with torch.cuda.stream(loop), _ffi.thread_concurrency(self._hint_value(lanes) if self._shape_hint in ('loop', 'all') else 1):
             self._run_loop(correlation, st, self.iters_pred, out, final_only)
             done = torch.cuda.Event()
             done.record(loop)
