@@ -44,6 +44,13 @@ import os
 import sys
 import time
 
+# N > 1: besides the caller's stream and the three loop lanes a rank drives a gather stream and RCCL's own -- six streams on HIP's four
+# default hardware queues would put a collective (a kernel that waits for its peers) in front of a loop's launches.  Eight queues keep
+# every stream on a queue of its own; a single-GPU run (four streams) is left on the default (measured identical with 4 / 8 / 16:
+# profiles/r12b_lanes_ab_per_process.txt).  Must be in the environment before the HIP runtime initialises.
+if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np
 import torch
 
@@ -644,6 +651,7 @@ def main():
         'loop_streams': ('one stream per loop (single-stream schedule), one lane per loop in flight' if model.lanes > 1 else
                          'three streams per loop (chain + flow branch + mask branch)') if pipelined else 'three streams per loop, calls serial',
         'launch_shape_hint': conc, 'launch_shape_hint_scope': model._shape_hint if conc > 1 else 'none',
+        'hip_hardware_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default (4)'),
         'note': 'the timed region is K back-to-back model([a, b]) calls between two device synchronisations: every kernel of every call is '
                 'inside it.  Consecutive calls are independent; call n runs its loop on lane n % loops_in_flight while the next calls\' '
                 'encoders, volume builds and loops proceed (tf_raft_amd/model.py "pipelined forward"); per-call results equal the serial '

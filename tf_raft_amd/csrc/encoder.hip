@@ -343,7 +343,7 @@ static int encoder_impl(const raft_encoder_weights *w, const float *images, cons
         const EncKind k1 = stride == 2 ? ENC_3x3_S2 : ENC_3x3_S1;
         const int ni = 1 + blk * 3;   // index of this block's norm1 in in_gamma / in_beta
         const bool w4 = ((wino4_mask >> (blk / 2)) & 1) &&
-                        (wino4_forced || (int64_t)n * ((Ho + 7) / 8) * ((Wo + 63) / 64) * ((F + 63) / 64) > 256);
+                        (wino4_forced || (int64_t)n * ((Ho + 7) / 8) * ((Wo + 63) / 64) * ((F + 63) / 64) * raft_concurrency() > 256);   // loops sharing the chip: the launch counts raft_concurrency() times (378.7 against 375.6 pairs/s with every stage on F(4x4) under three lanes, profiles/r12l_*)
         const raft_conv_weights *w44a = w4 ? &w->block_w44[blk][0] : nullptr, *w44b = w4 ? &w->block_w44[blk][1] : nullptr;
         if (inorm) {
             RAFT_TRY(conv(k1, c1, x, C, Hc, Wc, Ho, Wo, p1t, p1l, F, EPI_LINEAR, b.r1, nullptr, nullptr, nullptr, 0,
