@@ -208,7 +208,13 @@ class RAFT:
         return role if lane == 0 else f'{role}{lane}'
 
     def _loop_priority(self):
-        return -1 if os.environ.get('RAFT_LOOP_PRIORITY', '0') == '1' else 0
+        """Stream priority of the loop lanes: high (-1) when several loops are in flight -- their dependent chains are then dispatched ahead
+        of the next calls' chip-filling pre-loop kernels (379.4 / 380.0 against 376.9 / 377.0 pairs/s at 4 pairs, A/B/A/B in separate
+        processes, profiles/r12n_steps_and_priority.txt); RAFT_LOOP_PRIORITY = 0 / 1 overrides."""
+        v = os.environ.get('RAFT_LOOP_PRIORITY')
+        if v is not None:
+            return -1 if v == '1' else 0
+        return -1 if (self.pipeline and self.lanes > 1) else 0
 
     def _lane_entry(self, dev):
         """(device, (flow stream, mask stream), loop-context handle or None) of the current lane."""
