@@ -169,16 +169,32 @@ def stream_ptr() -> int:
 _SIDE_STREAMS = {}
 
 
-def side_stream(device, role: str, priority: int = 0) -> 'torch.cuda.Stream':
+# Priority of EVERY side stream of the package (one pool: streams of two priorities come from two pools whose members collide on the
+# hardware queues, see model.py _loop_priority).  RAFT_STREAM_PRIORITY=-1: all of them high -- i.e. above the caller's stream.
+import os as _os
+STREAM_PRIORITY = int(_os.environ.get('RAFT_STREAM_PRIORITY', '0'))
+
+
+def side_stream(device, role: str, priority: int = None) -> 'torch.cuda.Stream':
     """The process-wide side stream of ``role`` ('flow', 'mask', 'encoder', 'loop'; lane k > 0 of the pipelined forward:
     'loop1', 'flow1', ...) and ``priority`` on ``device``.  Streams of different priorities are different streams (a
     stream's priority is fixed when it is created)."""
     device = torch.device(device)
+    priority = STREAM_PRIORITY if priority is None else priority
     key = (device.index if device.index is not None else torch.cuda.current_device(), role, int(priority))
     s = _SIDE_STREAMS.get(key)
     if s is None:
         s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
     return s
+
+
+def reserve_streams(device, lanes: int = 3) -> None:
+    """Create the package's side streams on ``device`` in ONE canonical order the first time any model is built: the loop lanes
+    first, then the flow / mask / encoder streams of the serial schedule.  HIP assigns hardware queues in creation order, so this
+    makes the mapping of the lanes independent of which kind of model a process happens to build first (a multi-lane model built
+    after a serial one found its lanes on queues the serial streams had taken: 367 against 377 pairs/s, profiles/r12s_config_bench.txt)."""
+    for role in [('loop' if k == 0 else f'loop{k}') for k in range(lanes)] + ['flow', 'mask', 'encoder']:
+        side_stream(device, role)
 
 
 def i64_array(values):

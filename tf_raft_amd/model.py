@@ -112,7 +112,7 @@ class RAFT:
         self.loop_concurrency = 1 if loop_concurrency is None else max(1, int(loop_concurrency))
         self._lane_res = {}                      # lane -> (device, (flow stream, mask stream), raft_loop_ctx handle)
         self._loop_stream = None
-        _dev.require_gpu()
+        _dev.reserve_streams(_dev.require_gpu())
         _dev.lib()
         if weights is None:
             weights = weights_mod.init_weights(self.variant, seed)     # Keras default initialisers
@@ -208,13 +208,12 @@ class RAFT:
         return role if lane == 0 else f'{role}{lane}'
 
     def _loop_priority(self):
-        """Stream priority of the loop lanes: high (-1) when several loops are in flight -- their dependent chains are then dispatched ahead
-        of the next calls' chip-filling pre-loop kernels (379.4 / 380.0 against 376.9 / 377.0 pairs/s at 4 pairs, A/B/A/B in separate
-        processes, profiles/r12n_steps_and_priority.txt); RAFT_LOOP_PRIORITY = 0 / 1 overrides."""
-        v = os.environ.get('RAFT_LOOP_PRIORITY')
-        if v is not None:
-            return -1 if v == '1' else 0
-        return -1 if (self.pipeline and self.lanes > 1) else 0
+        """Stream priority of the loop lanes.  RAFT_LOOP_PRIORITY=1 (high) is worth +0.7 % in a process that creates nothing but one
+        multi-lane model (379.4 / 380.0 against 376.9 / 377.0 pairs/s, A/B/A/B, profiles/r12n_steps_and_priority.txt) and costs 10 - 70 %
+        in a process that also holds a serial model: priority streams come from a pool of their own, and the two pools' streams then
+        collide on HIP's four hardware queues (profiles/r12t_config_bench.txt: SmallRAFT 747 -> 597, a serial model after a multi-lane one
+        328 -> 187 pairs/s).  Not the default."""
+        return -1 if os.environ.get('RAFT_LOOP_PRIORITY', '0') == '1' else _dev.STREAM_PRIORITY
 
     def _lane_entry(self, dev):
         """(device, (flow stream, mask stream), loop-context handle or None) of the current lane."""
