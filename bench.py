@@ -15,7 +15,13 @@ batch (weak scaling) and the final predictions are all-gathered over RCCL inside
 N = 1 runs BASELINE configs[1] (batch 4 on the GPU); N > 1 runs configs[2]'s per-GPU shape (batch 8 per GPU: 64 pairs
 on 8 GPUs) unless --batch says otherwise.
 
+The timed model is built with pipeline=True (tf_raft_amd/model.py "pipelined forward"): consecutive calls are independent, call n's
+loop runs on lane n % 3 (a stream of its own) while the next calls' encoders, volume builds and loops proceed -- the timed region is
+still K complete model([a, b]) calls between two device synchronisations.  RAFT_PIPELINE=0 times the serial schedule.
+
 Rank 0 prints ONE JSON line; besides the contract fields it carries
+  schedule            what was timed: loops in flight, launch-shape hint, the same K steps on the serial schedule, the latency of ONE call
+                      consumed at once on both schedules
   final_iter_epe      the EPE half of BASELINE's metric ON THE TIMED CONFIGURATION: max-abs EPE of flow_predictions[-1] (element 0 of the
                       timed batch, Keras-default weights) against the CPU oracle; an untrained RAFT is ill conditioned there, so
                       final_iter_epe_within_tolerance is false and final_iter_epe_default_horizon says how far 1e-3 holds.
@@ -23,8 +29,12 @@ Rank 0 prints ONE JSON line; besides the contract fields it carries
                       iterations, horizon and locality per regime (default, conditioned, mid, jump0)
   pairs_per_s_by_regime  the same step timed in every regime (3 interleaved rounds, median): no data-dependent work
   roofline            the dominant kernel (by accumulated time): achieved = the FLOPs the kernel EXECUTES on the MFMA
-                      pipe per launch / its HIP-event time net of the calibrated event bracket; frac = achieved / 157.3 TF; `rocprof` =
-                      the same from the committed rocprofv3 durations (profiles/kernel_durations.json), with their staleness.  A layer on
+                      pipe per launch / its HIP-event time; frac = achieved / 157.3 TF.  With several loops in flight the kernel is
+                      launched in the shape of a larger batch (fewer, longer workgroups) and shares the chip with the other loops'
+                      kernels, so it is measured with the chip filled the same way: `instances` concurrent launches on as many
+                      streams, instances x FLOPs / the slowest stream's time per launch (`rocprof` = the rocprofv3 average duration of
+                      the same microbenchmark, profiles/kernel_concurrent.json); `single_instance` = one launch alone, with `rocprof`
+                      from the committed single-stream trace (profiles/kernel_durations.json), each with its staleness.  A layer on
                       a Winograd kernel executes fewer multiplies than the direct convolution it computes; the
                       direct-convolution figure is kept as algorithmic_tflops / frac_algorithmic (may exceed 1)
   roofline_lookup_convc1_fused, roofline_mask_upsample_fused   the kernels the product loop runs
