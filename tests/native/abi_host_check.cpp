@@ -121,14 +121,21 @@ int main() {
     for (int t = 0; t < 4; ++t)
         th.emplace_back([t, &go] {
             while (!go.load()) {}
+            // the launch-shape hint is THREAD-local: every thread sees only its own value, whatever the others set
+            EXPECT(raft_set_thread_concurrency(t + 2) == 1);
             for (int i = 0; i < 400; ++i) {
                 helpers_once(t * 1000 + i);
                 options_once(t + i);
                 if ((i & 63) == 0) rejects();
+                EXPECT(raft_set_thread_concurrency(t + 2) == t + 2);
             }
+            EXPECT(raft_set_thread_concurrency(0) == t + 2);       // n < 1 restores the default ...
+            EXPECT(raft_set_thread_concurrency(1000) == 1);        // ... and large values are clamped
+            EXPECT(raft_set_thread_concurrency(1) == 64);
         });
     go.store(1);
     for (auto &x : th) x.join();
+    EXPECT(raft_set_thread_concurrency(1) == 1);                   // the main thread never saw the workers' hints
     raft_set_option("RAFT_CORR_XCD", nullptr);
     raft_set_option("RAFT_LOOKUP_FUSED", nullptr);
     if (failures) {
