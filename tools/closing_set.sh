@@ -37,6 +37,10 @@ rm -rf $out/${tag}_ss_b4 $out/${tag}_ss_b8 $out/${tag}_ss_b16
 if [ -z "${SKIP_PMC:-}" ]; then
   bash tools/pmc_traffic.sh $tag 8 > $out/${tag}_pmc_traffic.txt 2>&1
   rm -rf $out/${tag}_pmc
+  # the same passes at the bench line's own batch (4 pairs: a 275 MB volume, which straddles the 256 MiB Infinity Cache)
+  bash tools/pmc_traffic.sh ${tag}b4 4 > $out/${tag}_pmc_traffic_b4.txt 2>&1
+  rm -rf $out/${tag}b4_pmc
+  [ -f $out/${tag}b4_pmc_traffic.json ] && cp $out/${tag}b4_pmc_traffic.json profiles/pmc_traffic_b4.json
 fi
 # the bench line reads the two summaries just made (the same library is loaded: not stale)
 [ -f $out/${tag}_kernel_durations.json ] && cp $out/${tag}_kernel_durations.json profiles/kernel_durations.json
