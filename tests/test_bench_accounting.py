@@ -73,9 +73,16 @@ def test_pmc_traffic_scales_the_committed_pass_per_pair():
         assert entry['batch'] >= 8
         tr4, note = bench.pmc_traffic(kernel, 4)
         tr8, _ = bench.pmc_traffic(kernel, 8)
+        tr2, note2 = bench.pmc_traffic(kernel, 2)            # no pass at 2 pairs: the 8-pair pass scaled per pair
         assert tr8 == pytest.approx(entry['hbm_bytes_per_launch'] * 8 / entry['batch'], abs=1)
-        assert tr4 == pytest.approx(tr8 / 2, abs=1)
-        assert note['pass_batch'] == entry['batch'] and note['scaled_to_batch'] == 4
+        assert tr2 == pytest.approx(tr8 / 4, abs=1) and note2['pass_batch'] == entry['batch'] and note2['scaled_to_batch'] == 2
+        # round 6: a pass taken AT the run's batch (profiles/pmc_traffic_b4.json) is preferred over scaling -- unless it is stale
+        b4, ev4 = bench.evidence_file('pmc_traffic_b4.json')
+        if b4 and not ev4['stale'] and kernel in b4:
+            assert note['pass_batch'] == 4 and tr4 == b4[kernel]['hbm_bytes_per_launch']
+        else:
+            assert tr4 == pytest.approx(tr8 / 2, abs=1) and note['pass_batch'] == entry['batch']
+        assert note['scaled_to_batch'] == 4
         if kernel != 'corr_build':
             assert note['in_loop'] is True
         # traffic never below the algorithmic bytes of the kernel (a pass that under-counts would flatter the kernel)
