@@ -493,8 +493,8 @@ def train_bench(args, world, rank, device, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)     # the driver's values; with several loops in flight a short timed region is
+    ap.add_argument('--warmup', type=int, default=5)     # mostly ramp and drain (5 steps: 324 pairs/s, 20: 377, 80: 385)
     ap.add_argument('--batch', type=int, default=None,
                     help='image pairs per GPU per step (default: 4 on one GPU = BASELINE configs[1]; 8 per GPU on N > 1 '
                          'GPUs = configs[2], 64 pairs on 8 GPUs)')
