@@ -52,6 +52,10 @@
  *                            events only order streams of one device, +0.4 .. 0.9 % on the three-stream loop, profiles/r10c_event_fence.txt)
  *   RAFT_CORR_XCD       0/1/n  volume build: plain (n, m, batch) tile grid / one region of the tile plane per XCD, walked in strips
  *                            of 2 (n >= 2: n) column tiles                                          (default 1)
+ *   RAFT_CORR_POOL      0/1  volume build: pyramid level 1 as extra GEMM columns against the pooled fmap2 / pooled from the level-0
+ *                            accumulators in the epilogue (2x2 averages by two DPP adds; 18 % fewer workgroups; the reference's own
+ *                            summation order, corr.py:106-114).  1 needs even map sizes and an even number of 4x8 tiles per
+ *                            row and column (448x512 and 1024x1024 frames have them), else 0 is used         (default 1)
  *   RAFT_ONDEMAND_BLOCK 0/1  on-demand lookup: wave per query / 4x8 query blocks on MFMA         (default 1)
  *   RAFT_LOOP_GRAPH     0/1  three-stream loops replayed as one hipGraph launch                  (default 0: measured
  *                       slower than stream launches on ROCm 7.2 at every batch size)

@@ -112,6 +112,40 @@ def test_corr_build_xcd_tile_order_is_bitwise_the_plain_grid(rng, shape, raft_op
     assert torch.equal(plain, xcd)
 
 
+@pytest.mark.parametrize('shape', [(2, 56, 64, 256), (1, 8, 16, 64), (2, 24, 32, 128), (1, 46, 62, 256), (1, 128, 128, 64), (3, 16, 48, 256)])
+def test_corr_build_level1_pooled_in_the_epilogue_matches_the_gemm_columns(rng, shape, raft_opt):
+    """Round 6: pyramid level 1 = 2x2 averages of the level-0 ACCUMULATORS (two DPP adds per register in the volume build's epilogue:
+    the reference's own order, corr.py:106-114) instead of extra GEMM columns against the pooled fmap2.  Both forms of the same
+    linear map: every level of both pyramids within the float64 bound of test_corr_build_matches_oracle_pyramid, the two level-1
+    volumes within a few ulps of each other, levels 0 / 2 / 3 and every padding float bit-identical; map sizes with ragged
+    query tiles (N < 128), the benchmarked map, the training crop, a 1024 x 1024 frame's map."""
+    import oracle
+    from tf_raft_amd.layers.corr import CorrBlock
+    B, h, w, C = shape
+    f1 = rng.normal(size=shape).astype(np.float32)
+    f2 = rng.normal(size=shape).astype(np.float32)
+    raft_opt.set('RAFT_CORR_POOL', '0')
+    cols = CorrBlock(f1, f2, num_levels=4, radius=4)
+    raft_opt.set('RAFT_CORR_POOL', '1')
+    pooled = CorrBlock(f1, f2, num_levels=4, radius=4)
+    ref64 = oracle.CorrBlock(_t(f1).double(), _t(f2).double(), num_levels=4, radius=4)
+    ref32 = oracle.CorrBlock(_t(f1), _t(f2), num_levels=4, radius=4)
+    off = list(pooled._off)
+    a, b = cols._pyr.cpu().numpy(), pooled._pyr.cpu().numpy()
+    for l in (0, 2, 3):
+        np.testing.assert_array_equal(a[off[l]:off[l + 1]], b[off[l]:off[l + 1]])            # same GEMM columns, padding included
+    l1a, l1b = a[off[1]:off[2]], b[off[1]:off[2]]
+    assert np.array_equal(l1a == 0, l1b == 0) or int(((l1a == 0) != (l1b == 0)).sum()) <= 2     # the padding of the maps is zero in both
+    g1, g0 = _np(pooled.corr_pyramid[1]), _np(cols.corr_pyramid[1])
+    r64 = ref64.corr_pyramid[1].numpy()
+    err_ref = float(np.abs(ref32.corr_pyramid[1].numpy() - r64).max())
+    err_pooled, err_cols = float(np.abs(g1 - r64).max()), float(np.abs(g0 - r64).max())
+    report(f'corr_build level 1 {shape}', pooled_vs_f64=err_pooled, gemm_columns_vs_f64=err_cols, oracle32_vs_f64=err_ref,
+           pooled_vs_columns=float(np.abs(g1 - g0).max()))
+    assert err_pooled <= max(4 * err_ref, 2e-5) and err_cols <= max(4 * err_ref, 2e-5)
+    assert float(np.abs(g1 - g0).max()) <= 4e-6 * max(1.0, float(np.abs(r64).max()))
+
+
 def _device_corr_with_oracle_pyramid(f1, f2, levels, radius):
     """Device CorrBlock whose volume is overwritten with the oracle's values, so the lookup can be
     compared in isolation (bit-exact arithmetic expected)."""

@@ -69,7 +69,7 @@ enum RaftOptionId {
     RAFT_OPT_WINO_CK, RAFT_OPT_WINO1D_TM,
     RAFT_OPT_LOOKUP_FUSED, RAFT_OPT_ONDEMAND_BLOCK, RAFT_OPT_ENC_WINO, RAFT_OPT_LOOP_GRAPH,
     RAFT_OPT_WINO_KS, RAFT_OPT_CONV_WINO4, RAFT_OPT_WINO4_KS, RAFT_OPT_MASK_FUSED, RAFT_OPT_ENC_WINO4, RAFT_OPT_CONVC2_KS, RAFT_OPT_CONVF2_KS,
-    RAFT_OPT_EVENT_FENCE, RAFT_OPT_CORR_XCD,
+    RAFT_OPT_EVENT_FENCE, RAFT_OPT_CORR_XCD, RAFT_OPT_CORR_POOL,
     RAFT_OPT_COUNT
 };
 int raft_opt(int id, int dflt);

@@ -151,6 +151,9 @@ struct CorrGemmArgs {
     float sqrt_c, rcp_sqrt_c;
     int rcp_exact;   // sqrt(C) is a power of two
     int xcd_rm, xcd_rn, xcd_maxreg, tiles_m, tiles_n, xcd_gw;   // XCD-aware tile order (xcd_rm == 0: plain 3-D grid)
+    // pool1: pyramid level 1 has NO columns in the GEMM (col_off[1] == col_off[2]); it is pooled from the level-0 accumulators in the
+    // epilogue.  brow_skip = rows of the fmap2 pyramid workspace to skip behind level 0 (its level-1 rows), tx0 = level-0 tiles per row.
+    int pool1, brow_skip, tx0;
 };
 
 constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32, CG_LD = 36;
@@ -200,7 +203,7 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
         return;                                                 // workgroup-uniform: region smaller than the largest one
     }
     const float *A = p.a + (int64_t)b * p.N * p.C;
-    const float *Bm = p.bmat + (int64_t)b * p.T * p.C;
+    const float *Bm = p.bmat + (int64_t)b * (p.T + p.brow_skip) * p.C;
 
     // staging assignment: 128 rows x 8 float4 per operand tile -> 4 chunks per thread per operand
     const int srow = tid >> 3, sc4 = tid & 7;
@@ -211,7 +214,9 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
             int r = srow + 32 * i;
             // rows beyond the edge are clamped, not branched around (their products are never stored):
             // a conditional load becomes a branch + s_waitcnt per chunk and serialises the loads
-            const int ma = min(m0 + r, p.N - 1), nb = min(n0 + r, p.T - 1);
+            const int ma = min(m0 + r, p.N - 1);
+            int nb = min(n0 + r, p.T - 1);
+            nb += nb >= (int)p.col_off[1] ? p.brow_skip : 0;       // pool1: the workspace's level-1 rows take no part
             ra[i] = *(const f32x4 *)(A + (int64_t)ma * p.C + k0 + sc4 * 4);
             rb[i] = *(const f32x4 *)(Bm + (int64_t)nb * p.C + k0 + sc4 * 4);
         }
@@ -299,6 +304,41 @@ __global__ void __launch_bounds__(256) corr_gemm_kernel(CorrGemmArgs p) {
             }
         }
     }
+    // ---- pyramid level 1 pooled from the level-0 accumulators (reference corr.py:106-114: avg_pool2d of the level below).
+    // The wave's 64 columns are two level-0 map tiles (tx even, tx + 1) of one tile row ty: lane l31 = (y % 4) * 8 + x % 8 holds the
+    // target (y, x) of each.  Two DPP adds (lane ^ 1: the x pair; lane ^ 8: the y pair) leave the 2x2 sum in all four lanes of a
+    // group, so the four lanes store it for four DIFFERENT query rows (replica rho -> register 4 q + rho): 16 dword stores per lane
+    // instead of 64.  Level-1 tile (ty / 2, tx / 2), rows 2 (ty & 1) + (y % 4) / 2, columns 4 (tx & 1) + (x % 8) / 2: the wave writes
+    // one 64-byte half tile per query, the workgroup of tile row ty ^ 1 the other half.
+    const int nw0 = n0 + wn * 64;
+    if (p.pool1 && nw0 + 64 <= (int)p.col_off[1] && !(RAFT_GEMM_ABL & 2)) {   // wave-uniform
+        const int t = nw0 >> 5, ty = t / p.tx0, tx = t - ty * p.tx0;           // level-0 tile of j = 0 (tx even)
+        const int tx1n = p.tx0 >> 1;
+        const int rho = (l31 & 1) | ((l31 >> 2) & 2);
+        const int64_t map1 = p.g.map[1];
+        float *l1 = p.pyr + p.g.off[1] + (int64_t)b * p.N * map1 + ((ty >> 1) * tx1n + (tx >> 1)) * 32 + ((ty & 1) * 2 + (l31 >> 4)) * 8 +
+                    ((l31 & 7) >> 1);
+        const float sc = p.rcp_sqrt_c * 0.25f;                                  // exact: pool1 requires rcp_exact
+        const bool whole = m0 + CG_BM <= p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float s4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * q + e];
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1, 0, 3, 2]
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror 8
+                        s4[e] = v;
+                    }
+                    const float v = rho == 0 ? s4[0] : (rho == 1 ? s4[1] : (rho == 2 ? s4[2] : s4[3]));
+                    const int m = m0 + wm * 64 + i * 32 + rho + 8 * q + 4 * half;
+                    if (whole || m < p.N) l1[(int64_t)m * map1 + j * 4] = v * sc;
+                }
+    }
 }
 
 // Round 4, measured and not kept (profiles/r10j_gemm_ablation.txt, r10k_corr_pipe_ab.txt): the phases of this kernel add up --
@@ -328,20 +368,26 @@ extern "C" int raft_corr_build_f32(const float *fmap1, const float *fmap2, int B
     a.pyr = pyr;
     a.N = h * w;
     a.C = C;
-    int64_t t = 0;
-    for (int l = 0; l < RAFT_MAX_LEVELS + 1; ++l) a.col_off[l] = 0;
-    for (int l = 0; l < levels; ++l) {
-        a.col_off[l] = t;
-        t += a.g.map[l];
-    }
-    a.col_off[levels] = t;
-    a.T = (int)t;
     a.sqrt_c = sqrtf((float)C);
     a.rcp_sqrt_c = 1.0f / a.sqrt_c;
     {
         int e = 0;
         a.rcp_exact = frexpf(a.sqrt_c, &e) == 0.5f;   // mantissa 0.5 <=> power of two: x / 2^k == x * 2^-k exactly
     }
+    // Level 1 from the level-0 accumulators (RAFT_CORR_POOL, default on) where every level-1 tile is covered by whole level-0 tiles
+    // of one workgroup row: even map sizes, an even number of level-0 tiles per row and column, exact 1 / sqrt(C).
+    a.tx0 = raft_tiles_x(w);
+    const int ty0 = (int)(a.g.map[0] / 32) / a.tx0;
+    a.pool1 = levels >= 2 && raft_opt(RAFT_OPT_CORR_POOL, 1) != 0 && a.rcp_exact && h % 2 == 0 && w % 2 == 0 && a.tx0 % 2 == 0 && ty0 % 2 == 0;
+    a.brow_skip = a.pool1 ? a.g.map[1] : 0;
+    int64_t t = 0;
+    for (int l = 0; l < RAFT_MAX_LEVELS + 1; ++l) a.col_off[l] = 0;
+    for (int l = 0; l < levels; ++l) {
+        a.col_off[l] = t;
+        t += (a.pool1 && l == 1) ? 0 : a.g.map[l];     // pooled: level 1 has no GEMM columns (col_off[1] == col_off[2])
+    }
+    a.col_off[levels] = t;
+    a.T = (int)t;
     a.tiles_m = (int)raft_ceil_div(a.N, CG_BM);
     a.tiles_n = (int)raft_ceil_div(a.T, CG_BN);
     a.xcd_rm = a.xcd_rn = a.xcd_maxreg = 0;

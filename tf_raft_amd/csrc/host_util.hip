@@ -58,7 +58,7 @@ const char *const kOptNames[RAFT_OPT_COUNT] = {
     "RAFT_WINO_CK", "RAFT_WINO1D_TM",
     "RAFT_LOOKUP_FUSED", "RAFT_ONDEMAND_BLOCK", "RAFT_ENC_WINO", "RAFT_LOOP_GRAPH",
     "RAFT_WINO_KS", "RAFT_CONV_WINO4", "RAFT_WINO4_KS", "RAFT_MASK_FUSED", "RAFT_ENC_WINO4", "RAFT_CONVC2_KS", "RAFT_CONVF2_KS",
-    "RAFT_EVENT_FENCE", "RAFT_CORR_XCD",
+    "RAFT_EVENT_FENCE", "RAFT_CORR_XCD", "RAFT_CORR_POOL",
 };
 constexpr int kTileEntries = 16;
 struct TileRule {
