@@ -192,7 +192,7 @@ def reserve_streams(device, lanes: int = 3) -> None:
     """Create the package's side streams on ``device`` in ONE canonical order the first time any model is built: the loop lanes
     first, then the flow / mask / encoder streams of the serial schedule.  HIP assigns hardware queues in creation order, so this
     makes the mapping of the lanes independent of which kind of model a process happens to build first (a multi-lane model built
-    after a serial one found its lanes on queues the serial streams had taken: 367 against 377 pairs/s, profiles/r12v_config_bench.txt)."""
+    after a serial one found its lanes on queues the serial streams had taken: 367 against 377 pairs/s, profiles/r12w_config_bench.txt)."""
     for role in [('loop' if k == 0 else f'loop{k}') for k in range(lanes)] + ['flow', 'mask', 'encoder']:
         side_stream(device, role)
 
